@@ -1,0 +1,85 @@
+// Global-norm clip + Adam over the flat parameter arena: one read of (theta, g, m, v), one
+// write of (theta, m, v) — 28 B per parameter, plus a 4 B/param norm pass when clipping.
+//   clip : tf.clip_by_global_norm, g * c / max(||g||, c)   (baselines/ppo2/common_functions.py:59-60,
+//          live use baselines/a2c/a2c.py:40-42)
+//   Adam : baselines/common/mpi_adam.py:30-35 with epsilon 1e-5 (common_functions.py:51-52)
+#include "kernels.hpp"
+
+namespace ppo2hip {
+
+constexpr int kNormBlocks = 256;
+constexpr int kScratchHeader = 64;   // bytes: [0] float global norm, [1] float applied scale
+
+__global__ void sumsq_partial_kernel(const float *__restrict__ g, int64_t P, float gscale, double *__restrict__ partial) {
+    __shared__ double red[17];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = (double)(g[i] * gscale);
+        s += x * x;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void adam_kernel(float *__restrict__ theta, const float *__restrict__ g, float *__restrict__ m,
+                            float *__restrict__ v, int64_t P, float a, float beta1, float beta2, float eps,
+                            float gscale, float max_norm, const double *__restrict__ partial, int npartial,
+                            float *__restrict__ header) {
+    __shared__ float scale_s;
+    if (threadIdx.x == 0) {
+        float scale = gscale;
+        if (max_norm > 0.f) {
+            double ss = 0.0;
+            for (int b = 0; b < npartial; b++) ss += partial[b];
+            const float norm = (float)sqrt(ss);
+            scale = gscale * (max_norm / fmaxf(norm, max_norm));
+            if (blockIdx.x == 0) header[0] = norm;
+        }
+        if (blockIdx.x == 0) header[1] = scale;
+        scale_s = scale;
+    }
+    __syncthreads();
+    const float scale = scale_s;
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * scale;
+        const float mi = beta1 * m[i] + omb1 * gi;
+        const float vi = beta2 * v[i] + omb2 * (gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        theta[i] += (-a) * mi / (sqrtf(vi) + eps);
+    }
+}
+
+}  // namespace ppo2hip
+
+using namespace ppo2hip;
+
+extern "C" size_t ppo2hip_adam_scratch_bytes(int64_t P) {
+    (void)P;
+    return kScratchHeader + kNormBlocks * sizeof(double);
+}
+
+extern "C" int ppo2hip_adam_step(float *params, const float *grads, float *m, float *v, int64_t P, double lr,
+                                 int64_t t, double beta1, double beta2, double epsilon, double grad_scale,
+                                 double max_grad_norm, void *scratch, void *stream) {
+    PPO2HIP_REQUIRE(P >= 0 && t >= 1, "adam_step: bad P=%lld t=%lld", (long long)P, (long long)t);
+    if (P == 0) return PPO2HIP_OK;
+    PPO2HIP_REQUIRE(params && grads && m && v && scratch, "adam_step: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    float *header = (float *)scratch;
+    double *partial = (double *)((char *)scratch + kScratchHeader);
+    int npartial = 0;
+    if (max_grad_norm > 0.0) {
+        npartial = (int)(ceil_div(P, 1024) < kNormBlocks ? ceil_div(P, 1024) : kNormBlocks);
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(npartial), dim3(256), 0, s, grads, P, (float)grad_scale, partial);
+        int rc = check_launch("sumsq_partial_kernel");
+        if (rc) return rc;
+    }
+    const double a = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
+    const int64_t nb = ceil_div(P, 1024) < 1024 ? ceil_div(P, 1024) : 1024;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, params, grads, m, v, P, (float)a,
+                       (float)beta1, (float)beta2, (float)epsilon, (float)grad_scale, (float)max_grad_norm, partial,
+                       npartial, header);
+    return check_launch("adam_kernel");
+}

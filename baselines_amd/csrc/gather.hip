@@ -1,0 +1,116 @@
+// Minibatch gather: what `arr[mbinds]` does for the seven arrays at
+// baselines/ppo2/ppo2.py:117, read straight out of the time-major rollout (the sf01
+// flatten never materialises), fused with the advantage normalisation of
+// baselines/ppo2/common_functions.py:67.
+#include "kernels.hpp"
+
+namespace ppo2hip {
+
+// one 4-byte (or 1-byte) word of one observation row per loop trip
+template <class W>
+__global__ void gather_rows_kernel(const W *__restrict__ src, const int32_t *__restrict__ idx, int64_t B,
+                                   int64_t row_words, int T, int E, W *__restrict__ dst) {
+    const int64_t total = B * row_words;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = g / row_words, w = g - i * row_words;
+        const int64_t smp = idx ? (int64_t)idx[i] : i;
+        dst[g] = src[tm_offset(smp, T, E) * row_words + w];
+    }
+}
+
+// 16-byte words for big, aligned rows (image observations)
+__global__ void gather_rows16_kernel(const uint4 *__restrict__ src, const int32_t *__restrict__ idx, int64_t B,
+                                     int64_t row_words, int T, int E, uint4 *__restrict__ dst) {
+    const int64_t i = blockIdx.x;
+    const int64_t smp = idx ? (int64_t)idx[i] : i;
+    const uint4 *s = src + tm_offset(smp, T, E) * row_words;
+    uint4 *d = dst + i * row_words;
+    for (int64_t w = threadIdx.x; w < row_words; w += blockDim.x) d[w] = s[w];
+}
+
+struct SmallGather {
+    const float *returns, *values, *neglogpacs;
+    const void *advs;
+    const uint8_t *masks;
+    const void *actions;
+    int adv_f64, T, E, nvalue, ac_words;
+    const double *stats;
+    float *o_returns, *o_values, *o_neglogpacs, *o_advs;
+    uint8_t *o_masks;
+    uint32_t *o_actions;
+};
+
+__global__ void gather_small_kernel(SmallGather g, const int32_t *__restrict__ idx, int64_t B) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const int64_t smp = idx ? (int64_t)idx[i] : i;
+    const int64_t r = tm_offset(smp, g.T, g.E);
+    for (int k = 0; k < g.nvalue; k++) {
+        g.o_returns[i * g.nvalue + k] = g.returns[r * g.nvalue + k];
+        g.o_values[i * g.nvalue + k] = g.values[r * g.nvalue + k];
+    }
+    g.o_neglogpacs[i] = g.neglogpacs[r];
+    double a = g.adv_f64 ? ((const double *)g.advs)[r] : (double)((const float *)g.advs)[r];
+    if (g.stats) {
+        // (a - mean) / (std + 1e-8), population std
+        const double n = g.stats[2];
+        const double mean = g.stats[0] / n;
+        double var = g.stats[1] / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        a = (a - mean) / (sqrt(var) + 1e-8);
+    }
+    g.o_advs[i] = (float)a;
+    if (g.o_masks) g.o_masks[i] = g.masks[r];
+    const uint32_t *act = (const uint32_t *)g.actions;
+    for (int k = 0; k < g.ac_words; k++) g.o_actions[i * g.ac_words + k] = act[r * g.ac_words + k];
+}
+
+__global__ void gather_states_kernel(const float *__restrict__ states, const int32_t *__restrict__ envs,
+                                     int nenv_mb, int width, float *__restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (int64_t)nenv_mb * width) return;
+    const int e = (int)(g / width), w = (int)(g - (int64_t)e * width);
+    out[g] = states[(int64_t)envs[e] * width + w];
+}
+
+int gather_minibatch(const GatherArgs &g, hipStream_t s) {
+    const ppo2hip_rollout *ro = g.ro;
+    const int64_t B = g.B;
+    if (B <= 0) return 0;
+    // observations
+    const bool a16 = (g.ob_bytes % 16 == 0) && ((uintptr_t)ro->obs % 16 == 0) && ((uintptr_t)g.obs % 16 == 0) && g.ob_bytes >= 1024;
+    if (a16) {
+        hipLaunchKernelGGL(gather_rows16_kernel, dim3((unsigned)B), dim3(256), 0, s, (const uint4 *)ro->obs, g.idx, B,
+                           g.ob_bytes / 16, ro->T, ro->E, (uint4 *)g.obs);
+    } else if (g.ob_bytes % 4 == 0) {
+        const int64_t total = B * (g.ob_bytes / 4);
+        const int64_t nb = ceil_div(total, 256) < 65536 ? ceil_div(total, 256) : 65536;
+        hipLaunchKernelGGL(gather_rows_kernel<uint32_t>, dim3((unsigned)nb), dim3(256), 0, s, (const uint32_t *)ro->obs,
+                           g.idx, B, g.ob_bytes / 4, ro->T, ro->E, (uint32_t *)g.obs);
+    } else {
+        const int64_t total = B * g.ob_bytes;
+        const int64_t nb = ceil_div(total, 256) < 65536 ? ceil_div(total, 256) : 65536;
+        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3((unsigned)nb), dim3(256), 0, s, (const uint8_t *)ro->obs,
+                           g.idx, B, g.ob_bytes, ro->T, ro->E, (uint8_t *)g.obs);
+    }
+    int rc = check_launch("gather_rows");
+    if (rc) return rc;
+    SmallGather sg;
+    sg.returns = ro->returns; sg.values = ro->values; sg.neglogpacs = ro->neglogpacs; sg.advs = ro->advs;
+    sg.masks = ro->masks; sg.actions = ro->actions; sg.adv_f64 = ro->adv_f64; sg.T = ro->T; sg.E = ro->E;
+    sg.nvalue = g.nvalue; sg.ac_words = (int)(g.ac_bytes / 4); sg.stats = g.stats;
+    sg.o_returns = g.returns; sg.o_values = g.values; sg.o_neglogpacs = g.neglogpacs; sg.o_advs = g.advs;
+    sg.o_masks = (g.masks && ro->masks) ? g.masks : nullptr; sg.o_actions = (uint32_t *)g.actions;
+    hipLaunchKernelGGL(gather_small_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, s, sg, g.idx, B);
+    return check_launch("gather_small");
+}
+
+int gather_states(const float *states, const int32_t *envs, int nenv_mb, int width, float *out, hipStream_t s) {
+    const int64_t total = (int64_t)nenv_mb * width;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(gather_states_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, states, envs,
+                       nenv_mb, width, out);
+    return check_launch("gather_states");
+}
+
+}  // namespace ppo2hip

@@ -1,0 +1,83 @@
+// Internal launch interface between the translation units of libppo2hip.
+#pragma once
+#include "common.hpp"
+
+namespace ppo2hip {
+
+enum Act { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };
+
+// ---- dense layers on the fp32 MFMA GEMM (gemm.hip) -------------------------------------
+// Y[M,N] = act(X[M,K] W[K,N] + b)      (accumulate: Y += X W (+ b), act must be ACT_NONE)
+int fc_forward(const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, int M, int N,
+               int K, int act, bool accumulate, hipStream_t s);
+// dX[M,Kin] = (dY[M,N] W^T) * act'(H)   H = saved activation of the layer that produced X (or null)
+int fc_dgrad(const float *dY, int lddy, const float *W, int Kin, int N, const float *H, int ldh, int act,
+             float *dX, int lddx, int M, bool accumulate, hipStream_t s);
+// slabs[z][(Kin+1), N]: rows 0..Kin-1 = X^T dY, row Kin = column sums of dY (the bias gradient),
+// each over the z-th slice of the S sample rows.  Returns the number of slabs written in *nslabs.
+int fc_wgrad_slabs(const float *X, int ldx, const float *dY, int lddy, int64_t S, int Kin, int N,
+                   float *slabs, int max_slabs, int *nslabs, hipStream_t s);
+int wgrad_max_slabs(int64_t S, int Kin, int N);
+// dst[i] (+)= sum_z slabs[z][i]
+int reduce_slabs(const float *slabs, int nslabs, int64_t size, float *dst, bool accumulate, hipStream_t s);
+
+// ---- convolution as implicit GEMM (conv.hip) -------------------------------------------
+struct ConvShape {
+    int B, IH, IW, Cin, KH, KW, stride, OH, OW, Cout;
+};
+// Y[B,OH,OW,Cout] = relu(conv(X) + b); X float32 NHWC, or uint8 NHWC scaled by 1/255 (x_u8)
+int conv_forward(const void *X, bool x_u8, const float *W, const float *b, float *Y, const ConvShape &c,
+                 hipStream_t s);
+// slabs[z][(KH*KW*Cin+1), Cout] as fc_wgrad_slabs
+int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape &c, float *slabs,
+                     int max_slabs, int *nslabs, hipStream_t s);
+int conv_wgrad_max_slabs(const ConvShape &c);
+// dX[B,IH,IW,Cin] = conv_transpose(dY, W) * relu'(Xact)   (Xact = the layer's float32 input activation)
+int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, const ConvShape &c, hipStream_t s);
+
+// ---- gather (gather.hip) ---------------------------------------------------------------
+struct GatherArgs {
+    const ppo2hip_rollout *ro;
+    const int32_t *idx;
+    int64_t B;
+    int64_t ob_bytes;   // bytes per observation row
+    int64_t ac_bytes;   // bytes per action row
+    int nvalue;
+    const double *stats;  // {sum, sumsq, count} or null
+    void *obs;
+    void *actions;
+    float *returns, *values, *neglogpacs, *advs;
+    uint8_t *masks;      // may be null
+};
+int gather_minibatch(const GatherArgs &g, hipStream_t s);
+int gather_states(const float *states, const int32_t *envs, int nenv_mb, int width, float *out, hipStream_t s);
+
+// ---- distributions + PPO loss (loss.hip) -----------------------------------------------
+struct LossArgs {
+    int dist, ac_dim, nvalue;
+    int64_t B;
+    const float *pi;       // [B, ac_dim]
+    const float *logstd;   // [ac_dim] (Gaussian)
+    const float *vf;       // [B, nvalue]
+    const void *actions;
+    const float *advs, *returns, *oldv, *oldnlp;
+    float cliprange;
+    ppo2hip_loss_desc cfg;
+    double inv_count;
+    float *dpi;            // [B, ac_dim] out
+    float *dvf;            // [B, nvalue] out
+    double *partial;       // scratch: loss_partial_count(B) * 16 doubles
+    float *losses;         // [8] out (device)
+    float *dlogstd;        // [ac_dim] out (Gaussian)
+};
+int loss_partial_blocks(int64_t B);
+int ppo_loss_backward(const LossArgs &a, hipStream_t s);
+int neglogp_rows(int dist, int ac_dim, const float *pi, const float *logstd, const void *actions, int64_t B,
+                 float *out, hipStream_t s);
+
+// ---- LSTM (lstm.hip) -------------------------------------------------------------------
+// elementwise gate kernels; the matrix products go through fc_forward / fc_dgrad / fc_wgrad_slabs
+int lstm_mask_state(const float *c_in, const float *h_in, const uint8_t *masks, int64_t mask_stride,
+                    int nenv, int nh, float *c_out, float *h_out, hipStream_t s);
+
+}  // namespace ppo2hip

@@ -1,0 +1,325 @@
+// Host-side orchestration: parameter arena layout, policy forward, and the minibatch
+// gradient (gather -> forward -> loss -> backward) as a fixed sequence of kernel launches
+// on the caller's stream.  No device memory is allocated here; scratch is carved from the
+// caller's workspace.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace ppo2hip {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct Var {
+    std::string name;
+    int64_t off;
+    int64_t shape[4];
+    int64_t size;
+};
+struct Layout {
+    std::vector<Var> vars;
+    int64_t total = 0;
+    void add(const char *name, int64_t d0, int64_t d1 = 0, int64_t d2 = 0, int64_t d3 = 0) {
+        Var v;
+        v.name = name;
+        v.off = total;
+        v.shape[0] = d0; v.shape[1] = d1; v.shape[2] = d2; v.shape[3] = d3;
+        v.size = d0 * (d1 ? d1 : 1) * (d2 ? d2 : 1) * (d3 ? d3 : 1);
+        total += v.size;
+        vars.push_back(v);
+    }
+    int64_t off(const char *name) const {
+        for (auto &v : vars)
+            if (v.name == name) return v.off;
+        return -1;
+    }
+};
+
+static bool is_recurrent(const ppo2hip_policy_desc &d) {
+    return d.kind == PPO2HIP_POLICY_CNN_LSTM || d.kind == PPO2HIP_POLICY_CNN_LNLSTM;
+}
+
+// conv output size, VALID padding
+static int conv_out(int in, int k, int s) { return (in - k) / s + 1; }
+
+static int build_layout(const ppo2hip_policy_desc &d, Layout &L) {
+    if (d.ac_dim < 1 || d.nvalue < 1 || d.nvalue > 8) {
+        set_error("policy_desc: ac_dim=%d nvalue=%d out of range", d.ac_dim, d.nvalue);
+        return PPO2HIP_EINVAL;
+    }
+    const bool gauss = d.dist == PPO2HIP_DIST_GAUSSIAN;
+    if (d.kind == PPO2HIP_POLICY_MLP) {
+        if (d.ob_dim < 1 || d.hidden1 < 1 || d.hidden2 < 1) {
+            set_error("policy_desc: MLP needs ob_dim, hidden1, hidden2 >= 1");
+            return PPO2HIP_EINVAL;
+        }
+        auto actor = [&]() {
+            L.add("pi_fc1/w", d.ob_dim, d.hidden1); L.add("pi_fc1/b", d.hidden1);
+            L.add("pi_fc2/w", d.hidden1, d.hidden2); L.add("pi_fc2/b", d.hidden2);
+        };
+        auto head = [&]() {
+            L.add("pi/w", d.hidden2, d.ac_dim); L.add("pi/b", d.ac_dim);
+            if (gauss) L.add("logstd", 1, d.ac_dim);
+        };
+        auto value = [&]() {
+            L.add("vf_fc1/w", d.ob_dim, d.hidden1); L.add("vf_fc1/b", d.hidden1);
+            L.add("vf_fc2/w", d.hidden1, d.hidden2); L.add("vf_fc2/b", d.hidden2);
+            L.add("vf/w", d.hidden2, d.nvalue); L.add("vf/b", d.nvalue);
+        };
+        if (d.order == PPO2HIP_ORDER_FORK) { actor(); head(); value(); }       // ppo2/policies.py:139-149
+        else { actor(); value(); head(); }                                    // a2c/policies.py:123-129
+        return 0;
+    }
+    if (d.kind == PPO2HIP_POLICY_CNN || is_recurrent(d)) {
+        if (d.ob_h < 36 || d.ob_w < 36 || d.ob_c < 1 || d.nvalue != 1) {
+            set_error("policy_desc: CNN needs ob_h, ob_w >= 36, ob_c >= 1, nvalue == 1");
+            return PPO2HIP_EINVAL;
+        }
+        const int h1 = conv_out(d.ob_h, 8, 4), w1 = conv_out(d.ob_w, 8, 4);
+        const int h2 = conv_out(h1, 4, 2), w2 = conv_out(w1, 4, 2);
+        const int h3 = conv_out(h2, 3, 1), w3 = conv_out(w2, 3, 1);
+        L.add("c1/w", 8, 8, d.ob_c, 32); L.add("c1/b", 1, 32, 1, 1);   // bias kept [1,nf,1,1], a2c/utils.py:53
+        L.add("c2/w", 4, 4, 32, 64); L.add("c2/b", 1, 64, 1, 1);
+        L.add("c3/w", 3, 3, 64, 64); L.add("c3/b", 1, 64, 1, 1);
+        L.add("fc1/w", (int64_t)h3 * w3 * 64, 512); L.add("fc1/b", 512);
+        int feat = 512;
+        if (is_recurrent(d)) {
+            if (d.nlstm < 1) { set_error("policy_desc: nlstm must be >= 1"); return PPO2HIP_EINVAL; }
+            const int nh = d.nlstm;
+            if (d.kind == PPO2HIP_POLICY_CNN_LSTM) {                      // a2c/utils.py:90-92
+                L.add("lstm1/wx", 512, 4 * nh); L.add("lstm1/wh", nh, 4 * nh); L.add("lstm1/b", 4 * nh);
+            } else {                                                      // a2c/utils.py:120-131
+                L.add("lstm1/wx", 512, 4 * nh); L.add("lstm1/gx", 4 * nh); L.add("lstm1/bx", 4 * nh);
+                L.add("lstm1/wh", nh, 4 * nh); L.add("lstm1/gh", 4 * nh); L.add("lstm1/bh", 4 * nh);
+                L.add("lstm1/b", 4 * nh); L.add("lstm1/gc", nh); L.add("lstm1/bc", nh);
+            }
+            feat = nh;
+        }
+        L.add("pi/w", feat, d.ac_dim); L.add("pi/b", d.ac_dim);
+        L.add("v/w", feat, 1); L.add("v/b", 1);
+        return 0;
+    }
+    set_error("policy_desc: unknown kind %d", d.kind);
+    return PPO2HIP_EINVAL;
+}
+
+// ---------------------------------------------------------------------------------------
+// MLP: two separate tanh trunks
+// ---------------------------------------------------------------------------------------
+struct MlpBuf {
+    float *X, *RET, *OLDV, *NLP, *ADV;
+    void *ACT;
+    float *H1a, *H2a, *PI, *H1v, *H2v, *VF, *dPI, *dVF, *dZ2, *dZ1, *slabs;
+    double *loss_partial;
+    int max_slabs;
+    int64_t slab_elems;
+};
+
+static void carve_mlp(const ppo2hip_policy_desc &d, int64_t B, Carver &c, MlpBuf &w, bool grad) {
+    const int D = d.ob_dim, h1 = d.hidden1, h2 = d.hidden2, A = d.ac_dim, R = d.nvalue;
+    w.X = c.take<float>(B * D);
+    w.H1a = c.take<float>(B * h1); w.H2a = c.take<float>(B * h2); w.PI = c.take<float>(B * A);
+    w.H1v = c.take<float>(B * h1); w.H2v = c.take<float>(B * h2); w.VF = c.take<float>(B * R);
+    if (!grad) return;
+    w.ACT = c.take<float>(B * (d.dist == PPO2HIP_DIST_GAUSSIAN ? A : 1));
+    w.RET = c.take<float>(B * R); w.OLDV = c.take<float>(B * R); w.NLP = c.take<float>(B); w.ADV = c.take<float>(B);
+    w.dPI = c.take<float>(B * A); w.dVF = c.take<float>(B * R);
+    w.dZ2 = c.take<float>(B * h2); w.dZ1 = c.take<float>(B * h1);
+    int ms = 1;
+    int64_t se = 0;
+    const int kin[3] = {D, h1, h2};
+    const int nout_a[3] = {h1, h2, A}, nout_v[3] = {h1, h2, R};
+    for (int l = 0; l < 3; l++) {
+        for (int n : {nout_a[l], nout_v[l]}) {
+            const int s = wgrad_max_slabs(B, kin[l], n);
+            const int64_t e = (int64_t)s * (kin[l] + 1) * n;
+            if (s > ms) ms = s;
+            if (e > se) se = e;
+        }
+    }
+    w.max_slabs = ms;
+    w.slab_elems = se;
+    w.slabs = c.take<float>(se);
+    w.loss_partial = c.take<double>((int64_t)loss_partial_blocks(B) * 80);
+}
+
+static int mlp_forward(const ppo2hip_policy_desc &d, const Layout &L, const float *p, const MlpBuf &w, int64_t B,
+                       float *pi, float *vf, hipStream_t s) {
+    const int D = d.ob_dim, h1 = d.hidden1, h2 = d.hidden2, A = d.ac_dim, R = d.nvalue;
+    int rc;
+    if ((rc = fc_forward(w.X, D, p + L.off("pi_fc1/w"), p + L.off("pi_fc1/b"), w.H1a, h1, B, h1, D, ACT_TANH, false, s))) return rc;
+    if ((rc = fc_forward(w.H1a, h1, p + L.off("pi_fc2/w"), p + L.off("pi_fc2/b"), w.H2a, h2, B, h2, h1, ACT_TANH, false, s))) return rc;
+    if ((rc = fc_forward(w.H2a, h2, p + L.off("pi/w"), p + L.off("pi/b"), pi, A, B, A, h2, ACT_NONE, false, s))) return rc;
+    if ((rc = fc_forward(w.X, D, p + L.off("vf_fc1/w"), p + L.off("vf_fc1/b"), w.H1v, h1, B, h1, D, ACT_TANH, false, s))) return rc;
+    if ((rc = fc_forward(w.H1v, h1, p + L.off("vf_fc2/w"), p + L.off("vf_fc2/b"), w.H2v, h2, B, h2, h1, ACT_TANH, false, s))) return rc;
+    if ((rc = fc_forward(w.H2v, h2, p + L.off("vf/w"), p + L.off("vf/b"), vf, R, B, R, h2, ACT_NONE, false, s))) return rc;
+    return 0;
+}
+
+// weight + bias gradient of one fc layer into grads[off .. off + (Kin+1)*N)
+static int fc_wgrad_into(const float *X, int ldx, const float *dY, int lddy, int64_t S, int Kin, int N,
+                         const MlpBuf &w, float *dst, hipStream_t s) {
+    int ns = 0;
+    int rc = fc_wgrad_slabs(X, ldx, dY, lddy, S, Kin, N, w.slabs, w.max_slabs, &ns, s);
+    if (rc) return rc;
+    return reduce_slabs(w.slabs, ns, (int64_t)(Kin + 1) * N, dst, false, s);
+}
+
+static int mlp_trunk_backward(const float *X, int D, const float *H1, int h1, const float *H2, int h2,
+                              const float *dOut, int N, const float *p, float *g, int64_t o1, int64_t o2,
+                              int64_t oh, const MlpBuf &w, int64_t B, hipStream_t s) {
+    int rc;
+    if ((rc = fc_wgrad_into(H2, h2, dOut, N, B, h2, N, w, g + oh, s))) return rc;
+    if ((rc = fc_dgrad(dOut, N, p + oh, h2, N, H2, h2, ACT_TANH, w.dZ2, h2, B, false, s))) return rc;
+    if ((rc = fc_wgrad_into(H1, h1, w.dZ2, h2, B, h1, h2, w, g + o2, s))) return rc;
+    if ((rc = fc_dgrad(w.dZ2, h2, p + o2, h1, h2, H1, h1, ACT_TANH, w.dZ1, h1, B, false, s))) return rc;
+    if ((rc = fc_wgrad_into(X, D, w.dZ1, h1, B, D, h1, w, g + o1, s))) return rc;
+    return 0;
+}
+
+static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const Layout &L, const float *p,
+                    const ppo2hip_rollout &ro, const int32_t *idx, int64_t B, const double *stats, float cliprange,
+                    double inv_count, float *grads, float *losses, void *ws, size_t ws_bytes, hipStream_t s) {
+    Carver c(ws, ws_bytes);
+    MlpBuf w;
+    carve_mlp(d, B, c, w, true);
+    if (!c.ok) {
+        set_error("ppo_grad: workspace too small (%zu < %zu bytes)", ws_bytes, c.used());
+        return PPO2HIP_ENOSPACE;
+    }
+    const int D = d.ob_dim, h1 = d.hidden1, h2 = d.hidden2, A = d.ac_dim, R = d.nvalue;
+    const bool gauss = d.dist == PPO2HIP_DIST_GAUSSIAN;
+    GatherArgs g;
+    g.ro = &ro; g.idx = idx; g.B = B; g.ob_bytes = (int64_t)D * 4; g.ac_bytes = gauss ? (int64_t)A * 4 : 4;
+    g.nvalue = R; g.stats = stats; g.obs = w.X; g.actions = w.ACT; g.returns = w.RET; g.values = w.OLDV;
+    g.neglogpacs = w.NLP; g.advs = w.ADV; g.masks = nullptr;
+    int rc;
+    if ((rc = gather_minibatch(g, s))) return rc;
+    if ((rc = mlp_forward(d, L, p, w, B, w.PI, w.VF, s))) return rc;
+    LossArgs la;
+    la.dist = d.dist; la.ac_dim = A; la.nvalue = R; la.B = B; la.pi = w.PI;
+    la.logstd = gauss ? p + L.off("logstd") : nullptr; la.vf = w.VF; la.actions = w.ACT; la.advs = w.ADV;
+    la.returns = w.RET; la.oldv = w.OLDV; la.oldnlp = w.NLP; la.cliprange = cliprange; la.cfg = lc;
+    la.inv_count = inv_count; la.dpi = w.dPI; la.dvf = w.dVF; la.partial = w.loss_partial; la.losses = losses;
+    la.dlogstd = gauss ? grads + L.off("logstd") : nullptr;
+    if ((rc = ppo_loss_backward(la, s))) return rc;
+    if ((rc = mlp_trunk_backward(w.X, D, w.H1a, h1, w.H2a, h2, w.dPI, A, p, grads, L.off("pi_fc1/w"),
+                                 L.off("pi_fc2/w"), L.off("pi/w"), w, B, s))) return rc;
+    if ((rc = mlp_trunk_backward(w.X, D, w.H1v, h1, w.H2v, h2, w.dVF, R, p, grads, L.off("vf_fc1/w"),
+                                 L.off("vf_fc2/w"), L.off("vf/w"), w, B, s))) return rc;
+    return 0;
+}
+
+}  // namespace ppo2hip
+
+using namespace ppo2hip;
+
+extern "C" int ppo2hip_version(void) { return PPO2HIP_VERSION; }
+extern "C" const char *ppo2hip_last_error(void) { return g_err; }
+
+extern "C" int64_t ppo2hip_param_count(const ppo2hip_policy_desc *desc) {
+    if (!desc) { set_error("param_count: null desc"); return PPO2HIP_EINVAL; }
+    Layout L;
+    int rc = build_layout(*desc, L);
+    return rc ? rc : L.total;
+}
+
+extern "C" int ppo2hip_param_layout(const ppo2hip_policy_desc *desc, int max_vars, char (*names)[32],
+                                    int64_t *offsets, int64_t *shapes) {
+    if (!desc) { set_error("param_layout: null desc"); return PPO2HIP_EINVAL; }
+    Layout L;
+    int rc = build_layout(*desc, L);
+    if (rc) return rc;
+    const int n = (int)L.vars.size();
+    for (int i = 0; i < n && i < max_vars; i++) {
+        if (names) { std::strncpy(names[i], L.vars[i].name.c_str(), 31); names[i][31] = 0; }
+        if (offsets) offsets[i] = L.vars[i].off;
+        if (shapes) for (int k = 0; k < 4; k++) shapes[i * 4 + k] = L.vars[i].shape[k];
+    }
+    return n;
+}
+
+extern "C" size_t ppo2hip_forward_workspace_bytes(const ppo2hip_policy_desc *desc, int64_t B) {
+    if (!desc || B < 0) return 0;
+    if (desc->kind == PPO2HIP_POLICY_MLP) {
+        Carver c(nullptr, 0);
+        MlpBuf w;
+        carve_mlp(*desc, B, c, w, false);
+        return c.used();
+    }
+    return 0;
+}
+
+extern "C" size_t ppo2hip_grad_workspace_bytes(const ppo2hip_policy_desc *desc, int64_t B) {
+    if (!desc || B < 0) return 0;
+    if (desc->kind == PPO2HIP_POLICY_MLP) {
+        Carver c(nullptr, 0);
+        MlpBuf w;
+        carve_mlp(*desc, B, c, w, true);
+        return c.used();
+    }
+    return 0;
+}
+
+extern "C" int ppo2hip_policy_forward(const ppo2hip_policy_desc *desc, const float *params, const void *obs,
+                                      int64_t B, const uint8_t *masks, const float *states_in, float *pi,
+                                      float *vf, float *states_out, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
+    PPO2HIP_REQUIRE(desc && params && obs && pi && vf && B >= 0, "policy_forward: bad argument");
+    if (B == 0) return PPO2HIP_OK;
+    Layout L;
+    int rc = build_layout(*desc, L);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (desc->kind == PPO2HIP_POLICY_MLP) {
+        Carver c(workspace, workspace_bytes);
+        MlpBuf w;
+        carve_mlp(*desc, B, c, w, false);
+        if (!c.ok || !workspace) { set_error("policy_forward: workspace too small (%zu < %zu)", workspace_bytes, c.used()); return PPO2HIP_ENOSPACE; }
+        w.X = (float *)obs;   // observations are already a dense [B, ob_dim] block
+        return mlp_forward(*desc, L, params, w, B, pi, vf, s);
+    }
+    (void)masks; (void)states_in; (void)states_out;
+    set_error("policy_forward: policy kind %d not built yet", desc->kind);
+    return PPO2HIP_EUNSUPPORTED;
+}
+
+extern "C" int ppo2hip_neglogp(const ppo2hip_policy_desc *desc, const float *params, const float *pi,
+                               const void *actions, int64_t B, float *neglogp, void *stream) {
+    PPO2HIP_REQUIRE(desc && params && pi && actions && neglogp && B >= 0, "neglogp: bad argument");
+    Layout L;
+    int rc = build_layout(*desc, L);
+    if (rc) return rc;
+    const float *logstd = desc->dist == PPO2HIP_DIST_GAUSSIAN ? params + L.off("logstd") : nullptr;
+    return neglogp_rows(desc->dist, desc->ac_dim, pi, logstd, actions, B, neglogp, (hipStream_t)stream);
+}
+
+extern "C" int ppo2hip_ppo_grad(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss, const float *params,
+                                const ppo2hip_rollout *rollout, const int32_t *idx, int64_t B,
+                                const int32_t *mb_envs, int32_t nsteps_mb, const double *stats, float cliprange,
+                                double inv_count, float *grads, float *losses, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    PPO2HIP_REQUIRE(desc && loss && params && rollout && grads && losses && workspace && B >= 1,
+                    "ppo_grad: bad argument");
+    PPO2HIP_REQUIRE(rollout->obs && rollout->actions && rollout->returns && rollout->values &&
+                    rollout->neglogpacs && rollout->advs, "ppo_grad: rollout has null arrays");
+    PPO2HIP_REQUIRE(rollout->T == 0 || (rollout->T > 0 && rollout->E > 0), "ppo_grad: bad rollout shape");
+    Layout L;
+    int rc = build_layout(*desc, L);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (desc->kind == PPO2HIP_POLICY_MLP)
+        return mlp_grad(*desc, *loss, L, params, *rollout, idx, B, stats, cliprange, inv_count, grads, losses,
+                        workspace, workspace_bytes, s);
+    (void)mb_envs; (void)nsteps_mb;
+    set_error("ppo_grad: policy kind %d not built yet", desc->kind);
+    return PPO2HIP_EUNSUPPORTED;
+}

@@ -1,0 +1,204 @@
+// Reverse scans over the time-major rollout: GAE/returns, A2C discounted returns,
+// and the sf01 flatten.  HBM-bound: one lane per (env, channel) column, time walked
+// backwards, every access coalesced along the env axis.
+#include "common.hpp"
+
+// The float64 carry of the scans must round exactly as NumPy's separate multiply and add
+// do, so no operation in this file may be contracted into an fma: the Makefile builds this
+// file with -ffp-contract=off (a file-scope pragma is not honoured for device code here).
+
+namespace ppo2hip {
+
+constexpr int kMaxR = 8;
+struct GammaVec { double g[kMaxR]; };
+
+// Arithmetic of baselines/ppo2/common_functions.py:325-328 in the reference's evaluation
+// order, with explicit round-to-nearest double ops so the compiler cannot contract
+// them into FMAs: the float64 carry is then bit-identical to NumPy's.
+template <int UNROLL>
+__global__ void gae_kernel(const float *__restrict__ rewards, const float *__restrict__ values,
+                           const uint8_t *__restrict__ dones, const float *__restrict__ last_values,
+                           const uint8_t *__restrict__ last_dones, GammaVec gv, double lam, int T,
+                           int E, int R, float *__restrict__ advs, float *__restrict__ returns,
+                           float *__restrict__ advs_ori) {
+    const int64_t C = (int64_t)E * R;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int env = (int)(c / R);
+    const int r = (int)(c - (int64_t)env * R);
+    const double gamma = gv.g[r];
+    const double gl = __dmul_rn(gamma, lam);
+
+    double nextvalue = (double)last_values[c];
+    double nnt = 1.0 - (double)(last_dones[env] != 0);
+    double last = 0.0;
+
+    int t = T - 1;
+    // main loop: UNROLL independent loads in flight per lane, the carry chain is arithmetic only
+    for (; t - (UNROLL - 1) >= 0; t -= UNROLL) {
+        float rw[UNROLL], vl[UNROLL];
+        uint8_t dn[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int64_t off = (int64_t)(t - u) * C + c;
+            rw[u] = rewards[off];
+            vl[u] = values[off];
+            dn[u] = dones[(int64_t)(t - u) * E + env];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int64_t off = (int64_t)(t - u) * C + c;
+            const double v = (double)vl[u];
+            double delta = __dadd_rn((double)rw[u], __dmul_rn(__dmul_rn(gamma, nextvalue), nnt));
+            delta = __dsub_rn(delta, v);
+            last = __dadd_rn(delta, __dmul_rn(__dmul_rn(gl, nnt), last));
+            const float a = (float)last;
+            const float ret = __fadd_rn(a, vl[u]);
+            advs[off] = a;
+            returns[off] = ret;
+            if (advs_ori) advs_ori[off] = __fsub_rn(ret, vl[u]);
+            nextvalue = v;
+            nnt = 1.0 - (double)(dn[u] != 0);   // dones[t] masks the step from t-1 to t
+        }
+    }
+    for (; t >= 0; t--) {
+        const int64_t off = (int64_t)t * C + c;
+        const float vf = values[off];
+        const double v = (double)vf;
+        double delta = __dadd_rn((double)rewards[off], __dmul_rn(__dmul_rn(gamma, nextvalue), nnt));
+        delta = __dsub_rn(delta, v);
+        last = __dadd_rn(delta, __dmul_rn(__dmul_rn(gl, nnt), last));
+        const float a = (float)last;
+        const float ret = __fadd_rn(a, vf);
+        advs[off] = a;
+        returns[off] = ret;
+        if (advs_ori) advs_ori[off] = __fsub_rn(ret, vf);
+        nextvalue = v;
+        nnt = 1.0 - (double)(dones[(int64_t)t * E + env] != 0);
+    }
+}
+
+// r = reward + gamma*r*(1-done), baselines/a2c/utils.py:158; the scan starts from the
+// bootstrap value when the env's last done flag is clear (baselines/a2c/a2c.py:122-123).
+template <int UNROLL>
+__global__ void discount_kernel(const float *__restrict__ rewards, const uint8_t *__restrict__ dones,
+                                const float *__restrict__ last_values, double gamma, int T, int E,
+                                float *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    double r = 0.0;
+    if (last_values && dones[(int64_t)(T - 1) * E + e] == 0) r = (double)last_values[e];
+    int t = T - 1;
+    for (; t - (UNROLL - 1) >= 0; t -= UNROLL) {
+        float rw[UNROLL];
+        uint8_t dn[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            rw[u] = rewards[(int64_t)(t - u) * E + e];
+            dn[u] = dones[(int64_t)(t - u) * E + e];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            r = __dadd_rn((double)rw[u], __dmul_rn(__dmul_rn(gamma, r), 1.0 - (double)(dn[u] != 0)));
+            out[(int64_t)(t - u) * E + e] = (float)r;
+        }
+    }
+    for (; t >= 0; t--) {
+        const int64_t off = (int64_t)t * E + e;
+        r = __dadd_rn((double)rewards[off], __dmul_rn(__dmul_rn(gamma, r), 1.0 - (double)(dones[off] != 0)));
+        out[off] = (float)r;
+    }
+}
+
+// [T, E, row] -> [E, T, row].  Large rows: one workgroup streams one row.
+template <class W>
+__global__ void sf01_bigrow_kernel(const W *__restrict__ src, int T, int E, int64_t row_words,
+                                   W *__restrict__ dst) {
+    const int64_t rowid = blockIdx.x;  // over T*E source rows
+    const int t = (int)(rowid / E), e = (int)(rowid - (int64_t)t * E);
+    const W *s = src + rowid * row_words;
+    W *d = dst + ((int64_t)e * T + t) * row_words;
+    for (int64_t i = threadIdx.x; i < row_words; i += blockDim.x) d[i] = s[i];
+}
+
+// Small rows: a 16x16 tile of rows goes through LDS so both the reads (along env)
+// and the writes (along time) move contiguous segments.
+template <class W>
+__global__ void sf01_tile_kernel(const W *__restrict__ src, int T, int E, int row_words,
+                                 W *__restrict__ dst) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    W *tile = (W *)smem_raw;  // [16 e][16 t][row_words]
+    const int t0 = blockIdx.y * 16, e0 = blockIdx.x * 16;
+    const int seg = 16 * row_words;
+    for (int i = threadIdx.x; i < 16 * seg; i += blockDim.x) {
+        const int tl = i / seg, rem = i - tl * seg;
+        const int el = rem / row_words, w = rem - el * row_words;
+        const int t = t0 + tl, e = e0 + el;
+        if (t < T && e < E) tile[(el * 16 + tl) * row_words + w] = src[((int64_t)t * E + e) * row_words + w];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * seg; i += blockDim.x) {
+        const int el = i / seg, rem = i - el * seg;
+        const int tl = rem / row_words, w = rem - tl * row_words;
+        const int t = t0 + tl, e = e0 + el;
+        if (t < T && e < E) dst[((int64_t)e * T + t) * row_words + w] = tile[(el * 16 + tl) * row_words + w];
+    }
+}
+
+}  // namespace ppo2hip
+
+using namespace ppo2hip;
+
+extern "C" int ppo2hip_gae_f32(const float *rewards, const float *values, const uint8_t *dones,
+                               const float *last_values, const uint8_t *last_dones,
+                               const double *gamma, double lam, int T, int E, int R, float *advs,
+                               float *returns, float *advs_ori, void *stream) {
+    PPO2HIP_REQUIRE(T >= 0 && E >= 0 && R >= 1 && R <= kMaxR, "gae: bad shape T=%d E=%d R=%d (R <= %d)", T, E, R, kMaxR);
+    if (T == 0 || E == 0) return PPO2HIP_OK;
+    PPO2HIP_REQUIRE(rewards && values && dones && last_values && last_dones && gamma && advs && returns,
+                    "gae: null pointer");
+    GammaVec gv;
+    for (int i = 0; i < kMaxR; i++) gv.g[i] = i < R ? gamma[i] : 0.0;
+    const int64_t C = (int64_t)E * R;
+    const int block = C <= 65536 ? 64 : 256;   // few columns: spread them over more CUs
+    const int64_t grid = ceil_div(C, block);
+    hipLaunchKernelGGL(gae_kernel<8>, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, rewards,
+                       values, dones, last_values, last_dones, gv, lam, T, E, R, advs, returns, advs_ori);
+    return check_launch("gae_kernel");
+}
+
+extern "C" int ppo2hip_discount_with_dones_f32(const float *rewards, const uint8_t *dones,
+                                               const float *last_values, double gamma, int T, int E,
+                                               float *out, void *stream) {
+    PPO2HIP_REQUIRE(T >= 0 && E >= 0, "discount_with_dones: bad shape T=%d E=%d", T, E);
+    if (T == 0 || E == 0) return PPO2HIP_OK;
+    PPO2HIP_REQUIRE(rewards && dones && out, "discount_with_dones: null pointer");
+    const int block = E <= 65536 ? 64 : 256;
+    hipLaunchKernelGGL(discount_kernel<8>, dim3((unsigned)ceil_div(E, block)), dim3(block), 0,
+                       (hipStream_t)stream, rewards, dones, last_values, gamma, T, E, out);
+    return check_launch("discount_kernel");
+}
+
+extern "C" int ppo2hip_sf01(const void *src, int T, int E, int64_t row_bytes, void *dst, void *stream) {
+    PPO2HIP_REQUIRE(T >= 0 && E >= 0 && row_bytes > 0, "sf01: bad shape T=%d E=%d row_bytes=%lld", T, E, (long long)row_bytes);
+    if (T == 0 || E == 0) return PPO2HIP_OK;
+    PPO2HIP_REQUIRE(src && dst, "sf01: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const bool w4 = (row_bytes % 4 == 0) && ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0);
+    if (row_bytes >= 256) {
+        const int64_t rows = (int64_t)T * E;
+        PPO2HIP_REQUIRE(rows < (1ll << 31), "sf01: too many rows");
+        if (w4) hipLaunchKernelGGL(sf01_bigrow_kernel<uint32_t>, dim3((unsigned)rows), dim3(256), 0, s,
+                                   (const uint32_t *)src, T, E, row_bytes / 4, (uint32_t *)dst);
+        else hipLaunchKernelGGL(sf01_bigrow_kernel<uint8_t>, dim3((unsigned)rows), dim3(256), 0, s,
+                                (const uint8_t *)src, T, E, row_bytes, (uint8_t *)dst);
+    } else {
+        dim3 grid((unsigned)ceil_div(E, 16), (unsigned)ceil_div(T, 16));
+        const size_t lds = 256 * (size_t)row_bytes;
+        if (w4) hipLaunchKernelGGL(sf01_tile_kernel<uint32_t>, grid, dim3(256), lds, s, (const uint32_t *)src,
+                                   T, E, (int)(row_bytes / 4), (uint32_t *)dst);
+        else hipLaunchKernelGGL(sf01_tile_kernel<uint8_t>, grid, dim3(256), lds, s, (const uint8_t *)src, T,
+                                E, (int)row_bytes, (uint8_t *)dst);
+    }
+    return check_launch("sf01");
+}

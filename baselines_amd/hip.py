@@ -1,0 +1,389 @@
+"""Tensor-level wrappers over the C ABI: shape/dtype checks on the host, then one
+ppo2hip_* call on the current HIP stream.  torch tensors are only containers for
+device memory here; no torch operator computes anything on the path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a device tensor" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def _as_u8(t):
+    return t.view(torch.uint8) if t.dtype == torch.bool else t
+
+
+# --------------------------------------------------------------------------------------
+# scans
+# --------------------------------------------------------------------------------------
+
+def gae(rewards, values, dones, last_values, last_dones, gamma, lam, want_advs_ori=True):
+    """GAE over a time-major rollout ([T,E,R] float32); returns (advs, returns, advs_ori)."""
+    rewards = _dev(rewards, torch.float32, "rewards")
+    values = _dev(values, torch.float32, "values")
+    if rewards.dim() != 3 or values.shape != rewards.shape:
+        raise ValueError("rewards/values must both be [T, E, R]")
+    T, E, R = rewards.shape
+    dones = _dev(_as_u8(dones), torch.uint8, "dones")
+    last_dones = _dev(_as_u8(last_dones), torch.uint8, "last_dones")
+    last_values = _dev(last_values, torch.float32, "last_values")
+    if tuple(dones.shape) != (T, E) or last_dones.numel() != E or last_values.numel() != E * R:
+        raise ValueError("dones [T,E], last_dones [E], last_values [E,R] expected")
+    g = np.ascontiguousarray(np.broadcast_to(np.asarray(gamma, np.float64), (R,)))
+    advs = torch.empty_like(rewards)
+    rets = torch.empty_like(rewards)
+    ori = torch.empty_like(rewards) if want_advs_ori else None
+    check(lib.ppo2hip_gae_f32(_ptr(rewards), _ptr(values), _ptr(dones), _ptr(last_values), _ptr(last_dones),
+                              g.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), float(lam), T, E, R,
+                              _ptr(advs), _ptr(rets), _ptr(ori), _stream()), "gae")
+    return advs, rets, ori
+
+
+def discount_with_dones(rewards, dones, last_values, gamma):
+    """A2C n-step returns over time-major [T,E]; last_values None = no bootstrap."""
+    rewards = _dev(rewards, torch.float32, "rewards")
+    if rewards.dim() != 2:
+        raise ValueError("rewards must be [T, E]")
+    T, E = rewards.shape
+    dones = _dev(_as_u8(dones), torch.uint8, "dones")
+    if tuple(dones.shape) != (T, E):
+        raise ValueError("dones must be [T, E]")
+    if last_values is not None:
+        last_values = _dev(last_values, torch.float32, "last_values")
+        if last_values.numel() != E:
+            raise ValueError("last_values must be [E]")
+    out = torch.empty_like(rewards)
+    check(lib.ppo2hip_discount_with_dones_f32(_ptr(rewards), _ptr(dones), _ptr(last_values), float(gamma), T, E,
+                                              _ptr(out), _stream()), "discount_with_dones")
+    return out
+
+
+def sf01(arr):
+    """[T, E, ...] -> [E*T, ...] on device."""
+    if not arr.is_cuda or not arr.is_contiguous() or arr.dim() < 2:
+        raise ValueError("sf01 needs a contiguous device tensor with at least 2 dims")
+    T, E = arr.shape[0], arr.shape[1]
+    src = _as_u8(arr)
+    row_bytes = src.element_size()
+    for d in src.shape[2:]:
+        row_bytes *= d
+    out = torch.empty((T * E,) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+    check(lib.ppo2hip_sf01(_ptr(src), T, E, row_bytes, _ptr(out), _stream()), "sf01")
+    return out.view(arr.dtype) if arr.dtype == torch.bool else out
+
+
+# --------------------------------------------------------------------------------------
+# advantages
+# --------------------------------------------------------------------------------------
+
+def compute_advs(max_return, values, advs_ori):
+    """Fork scalarisation: values/advs_ori float32 [N,R] -> float64 [N]."""
+    values = _dev(values, torch.float32, "values")
+    advs_ori = _dev(advs_ori, torch.float32, "advs_ori")
+    if values.dim() != 2 or values.shape != advs_ori.shape:
+        raise ValueError("values/advs_ori must both be [N, R]")
+    N, R = values.shape
+    mr = np.ascontiguousarray(np.asarray(max_return, np.float64))
+    if mr.shape != (R,):
+        raise ValueError("max_return must have R entries")
+    wsb = lib.ppo2hip_compute_advs_workspace_bytes(N, R)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=values.device)
+    out = torch.empty(N, dtype=torch.float64, device=values.device)
+    check(lib.ppo2hip_compute_advs(_ptr(values), _ptr(advs_ori), mr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                   N, R, _ptr(ws), wsb, _ptr(out), _stream()), "compute_advs")
+    return out
+
+
+def adv_stats(advs, idx, B, nmb, T, E, workspace=None, out=None):
+    """{sum, sumsq, count} per minibatch (float64 [nmb,3], device)."""
+    if advs.dtype not in (torch.float32, torch.float64) or not advs.is_cuda or not advs.is_contiguous():
+        raise TypeError("advs must be a contiguous float32/float64 device tensor")
+    n_src = advs.numel()
+    if idx is not None:
+        idx = _dev(idx, torch.int32, "idx")
+        if idx.numel() < B * nmb:
+            raise ValueError("idx shorter than nmb*B")
+    elif n_src < B * nmb:
+        raise ValueError("advs shorter than nmb*B")
+    if T and T * E != n_src:
+        raise ValueError("advs must hold T*E entries")
+    wsb = lib.ppo2hip_adv_stats_workspace_bytes(nmb)
+    if workspace is None:
+        workspace = torch.empty(wsb, dtype=torch.uint8, device=advs.device)
+    elif workspace.numel() * workspace.element_size() < wsb:
+        raise ValueError("adv_stats workspace too small")
+    if out is None:
+        out = torch.empty((nmb, 3), dtype=torch.float64, device=advs.device)
+    check(lib.ppo2hip_adv_stats(_ptr(advs), int(advs.dtype == torch.float64), _ptr(idx), B, nmb, T, E,
+                                _ptr(workspace), _ptr(out), _stream()), "adv_stats")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# permutation (host)
+# --------------------------------------------------------------------------------------
+
+class LegacyShuffler:
+    """np.random.shuffle-compatible permutation source running in C++.
+
+    ``shuffle(inds)`` permutes a host int32/int64 NumPy array in place exactly as
+    ``np.random.shuffle`` would from the same MT19937 state.  ``adopt_numpy()`` /
+    ``release_numpy()`` move the global ``np.random`` stream in and out, so that a
+    caller mixing both sees one continuous stream, as the reference does.
+    """
+
+    def __init__(self, seed=0):
+        self._h = lib.ppo2hip_rng_create(int(seed) & 0xFFFFFFFF)
+        if not self._h:
+            raise MemoryError("ppo2hip_rng_create failed")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.ppo2hip_rng_destroy(h)
+
+    def seed(self, seed):
+        lib.ppo2hip_rng_seed(self._h, int(seed) & 0xFFFFFFFF)
+
+    def set_state(self, key, pos):
+        key = np.ascontiguousarray(key, np.uint32)
+        if key.shape != (624,):
+            raise ValueError("MT19937 key must have 624 words")
+        check(lib.ppo2hip_rng_set_state(self._h, key.ctypes.data_as(ctypes.c_void_p), int(pos)), "rng_set_state")
+
+    def get_state(self):
+        key = np.empty(624, np.uint32)
+        pos = ctypes.c_int(0)
+        check(lib.ppo2hip_rng_get_state(self._h, key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos)), "rng_get_state")
+        return key, pos.value
+
+    def adopt_numpy(self):
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            raise RuntimeError("global np.random is not the legacy MT19937 stream")
+        self._np_tail = st[3:]
+        self.set_state(st[1], st[2])
+
+    def release_numpy(self):
+        key, pos = self.get_state()
+        np.random.set_state(("MT19937", key, pos) + tuple(self._np_tail))
+
+    def shuffle(self, inds):
+        if not isinstance(inds, np.ndarray) or inds.ndim != 1 or not inds.flags.c_contiguous:
+            raise TypeError("inds must be a contiguous 1-D NumPy array")
+        p = inds.ctypes.data_as(ctypes.c_void_p)
+        if inds.dtype == np.int64:
+            check(lib.ppo2hip_shuffle_i64(self._h, p, inds.size), "shuffle")
+        elif inds.dtype == np.int32:
+            check(lib.ppo2hip_shuffle_i32(self._h, p, inds.size), "shuffle")
+        else:
+            raise TypeError("inds must be int32 or int64")
+        return inds
+
+
+# --------------------------------------------------------------------------------------
+# policy arena, forward, gradient, optimiser
+# --------------------------------------------------------------------------------------
+
+class PolicySpec:
+    """Python view of ppo2hip_policy_desc plus the arena layout it implies."""
+
+    def __init__(self, kind, dist, ac_dim, nvalue, ob_dim=0, ob_hwc=(0, 0, 0), hidden=(0, 0), order=_lib.ORDER_FORK,
+                 nlstm=0):
+        self.desc = _lib.PolicyDesc(kind, dist, order, ob_dim, ob_hwc[0], ob_hwc[1], ob_hwc[2], hidden[0], hidden[1],
+                                    ac_dim, nvalue, nlstm)
+        n = lib.ppo2hip_param_count(ctypes.byref(self.desc))
+        if n < 0:
+            check(int(n), "param_count")
+        self.nparams = int(n)
+        names = ((ctypes.c_char * 32) * 64)()
+        offs = (ctypes.c_int64 * 64)()
+        shapes = (ctypes.c_int64 * 256)()
+        nv = lib.ppo2hip_param_layout(ctypes.byref(self.desc), 64, names, offs, shapes)
+        if nv < 0:
+            check(nv, "param_layout")
+        self.vars = []
+        for i in range(nv):
+            shp = tuple(int(shapes[i * 4 + k]) for k in range(4) if shapes[i * 4 + k] != 0)
+            self.vars.append((names[i].value.decode(), int(offs[i]), shp))
+        self.kind, self.dist, self.ac_dim, self.nvalue, self.nlstm = kind, dist, ac_dim, nvalue, nlstm
+        self.ob_dim, self.ob_hwc = ob_dim, tuple(ob_hwc)
+        self.recurrent = kind in (_lib.POLICY_CNN_LSTM, _lib.POLICY_CNN_LNLSTM)
+
+    @property
+    def gaussian(self):
+        return self.dist == _lib.DIST_GAUSSIAN
+
+    def ob_shape(self):
+        return (self.ob_dim,) if self.kind == _lib.POLICY_MLP else self.ob_hwc
+
+    def ob_dtype(self):
+        return torch.float32 if self.kind == _lib.POLICY_MLP else torch.uint8
+
+    def views(self, arena):
+        """name -> view of `arena` (device or host tensor / ndarray) in creation order."""
+        out = {}
+        for name, off, shp in self.vars:
+            n = int(np.prod(shp))
+            out[name] = arena[off:off + n].reshape(shp)
+        return out
+
+    def forward_workspace_bytes(self, B):
+        return int(lib.ppo2hip_forward_workspace_bytes(ctypes.byref(self.desc), B))
+
+    def grad_workspace_bytes(self, B):
+        return int(lib.ppo2hip_grad_workspace_bytes(ctypes.byref(self.desc), B))
+
+
+def policy_forward(spec, params, obs, workspace, masks=None, states=None):
+    """obs [B, ...] -> (pi [B, ac_dim], vf [B, nvalue], new_states or None)."""
+    params = _dev(params, torch.float32, "params")
+    if params.numel() != spec.nparams:
+        raise ValueError("params has %d entries, policy needs %d" % (params.numel(), spec.nparams))
+    obs = _dev(obs, spec.ob_dtype(), "obs")
+    if tuple(obs.shape[1:]) != tuple(spec.ob_shape()):
+        raise ValueError("obs rows must have shape %s, got %s" % (spec.ob_shape(), tuple(obs.shape[1:])))
+    B = obs.shape[0]
+    need = spec.forward_workspace_bytes(B)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        raise ValueError("forward workspace too small: need %d bytes" % need)
+    pi = torch.empty((B, spec.ac_dim), dtype=torch.float32, device=obs.device)
+    vf = torch.empty((B, spec.nvalue), dtype=torch.float32, device=obs.device)
+    snew = None
+    if spec.recurrent:
+        masks = _dev(_as_u8(masks), torch.uint8, "masks")
+        states = _dev(states, torch.float32, "states")
+        if masks.numel() != B or tuple(states.shape) != (B, 2 * spec.nlstm):
+            raise ValueError("recurrent forward needs masks [B] and states [B, 2*nlstm]")
+        snew = torch.empty_like(states)
+    check(lib.ppo2hip_policy_forward(ctypes.byref(spec.desc), _ptr(params), _ptr(obs), B, _ptr(masks), _ptr(states),
+                                     _ptr(pi), _ptr(vf), _ptr(snew), _ptr(workspace),
+                                     workspace.numel() * workspace.element_size(), _stream()), "policy_forward")
+    return pi, vf, snew
+
+
+def neglogp(spec, params, pi, actions):
+    pi = _dev(pi, torch.float32, "pi")
+    B = pi.shape[0]
+    actions = _dev(actions, torch.float32 if spec.gaussian else torch.int32, "actions")
+    if actions.numel() != B * (spec.ac_dim if spec.gaussian else 1):
+        raise ValueError("actions has the wrong number of entries")
+    out = torch.empty(B, dtype=torch.float32, device=pi.device)
+    check(lib.ppo2hip_neglogp(ctypes.byref(spec.desc), _ptr(params), _ptr(pi), _ptr(actions), B, _ptr(out), _stream()),
+          "neglogp")
+    return out
+
+
+class RolloutRef:
+    """Checked view of the arrays a minibatch is drawn from (ppo2hip_rollout)."""
+
+    def __init__(self, spec, obs, actions, returns, values, neglogpacs, advs, T, E, masks=None, states=None):
+        n = T * E if T else obs.shape[0]
+        R = spec.nvalue
+        self.keep = (obs, actions, returns, values, neglogpacs, advs, masks, states)
+        _dev(obs, spec.ob_dtype(), "obs")
+        _dev(actions, torch.float32 if spec.gaussian else torch.int32, "actions")
+        _dev(returns, torch.float32, "returns")
+        _dev(values, torch.float32, "values")
+        _dev(neglogpacs, torch.float32, "neglogpacs")
+        if advs.dtype not in (torch.float32, torch.float64) or not advs.is_cuda or not advs.is_contiguous():
+            raise TypeError("advs must be a contiguous float32/float64 device tensor")
+        ob_elems = int(np.prod(spec.ob_shape()))
+        for t, cnt, name in ((obs, n * ob_elems, "obs"), (actions, n * (spec.ac_dim if spec.gaussian else 1), "actions"),
+                             (returns, n * R, "returns"), (values, n * R, "values"), (neglogpacs, n, "neglogpacs"),
+                             (advs, n, "advs")):
+            if t.numel() != cnt:
+                raise ValueError("%s holds %d entries, rollout needs %d" % (name, t.numel(), cnt))
+        if spec.recurrent:
+            masks = _dev(_as_u8(masks), torch.uint8, "masks")
+            states = _dev(states, torch.float32, "states")
+            if masks.numel() != n:
+                raise ValueError("masks must hold one flag per sample")
+        self.n = n
+        self.c = _lib.Rollout(obs.data_ptr(), actions.data_ptr(), returns.data_ptr(), values.data_ptr(),
+                              neglogpacs.data_ptr(), advs.data_ptr(),
+                              masks.data_ptr() if masks is not None else None,
+                              states.data_ptr() if states is not None else None,
+                              int(advs.dtype == torch.float64), T, E)
+
+
+def ppo_grad(spec, loss_desc, params, rollout, idx, B, stats, cliprange, inv_count, grads, losses, workspace,
+             mb_envs=None, nsteps_mb=0):
+    """One minibatch: gather + forward + loss + backward into `grads` / `losses` (device)."""
+    _dev(params, torch.float32, "params")
+    _dev(grads, torch.float32, "grads")
+    _dev(losses, torch.float32, "losses")
+    if params.numel() != spec.nparams or grads.numel() != spec.nparams or losses.numel() < 8:
+        raise ValueError("params/grads must have %d entries and losses at least 8" % spec.nparams)
+    if idx is not None:
+        _dev(idx, torch.int32, "idx")
+        if idx.numel() < B:
+            raise ValueError("idx shorter than B")
+    elif rollout.n < B:
+        raise ValueError("rollout shorter than B")
+    if stats is not None:
+        _dev(stats, torch.float64, "stats")
+        if stats.numel() < 3:
+            raise ValueError("stats needs 3 entries")
+    need = spec.grad_workspace_bytes(B)
+    have = workspace.numel() * workspace.element_size()
+    if have < need:
+        raise ValueError("grad workspace too small: need %d bytes, have %d" % (need, have))
+    if mb_envs is not None:
+        _dev(mb_envs, torch.int32, "mb_envs")
+    check(lib.ppo2hip_ppo_grad(ctypes.byref(spec.desc), ctypes.byref(loss_desc), _ptr(params), ctypes.byref(rollout.c),
+                               _ptr(idx), B, _ptr(mb_envs), nsteps_mb, _ptr(stats), float(cliprange),
+                               float(inv_count), _ptr(grads), _ptr(losses), _ptr(workspace), have, _stream()),
+          "ppo_grad")
+
+
+def adam_scratch(P, device):
+    return torch.zeros(int(lib.ppo2hip_adam_scratch_bytes(P)), dtype=torch.uint8, device=device)
+
+
+def adam_step(params, grads, m, v, lr, t, scratch, max_grad_norm=0.0, grad_scale=1.0, beta1=0.9, beta2=0.999,
+              epsilon=1e-5):
+    for x, name in ((params, "params"), (grads, "grads"), (m, "m"), (v, "v")):
+        _dev(x, torch.float32, name)
+    P = params.numel()
+    if grads.numel() != P or m.numel() != P or v.numel() != P:
+        raise ValueError("params/grads/m/v sizes differ")
+    if scratch.numel() * scratch.element_size() < lib.ppo2hip_adam_scratch_bytes(P):
+        raise ValueError("adam scratch too small")
+    check(lib.ppo2hip_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), P, float(lr), int(t), beta1, beta2,
+                                epsilon, float(grad_scale), float(max_grad_norm or 0.0), _ptr(scratch), _stream()),
+          "adam_step")
+
+
+def gemm(A, B):
+    A = _dev(A, torch.float32, "A")
+    B = _dev(B, torch.float32, "B")
+    M, K = A.shape
+    K2, N = B.shape
+    if K != K2:
+        raise ValueError("inner dimensions differ")
+    C = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    check(lib.ppo2hip_gemm_f32(_ptr(A), _ptr(B), _ptr(C), M, N, K, _stream()), "gemm")
+    return C

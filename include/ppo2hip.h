@@ -1,0 +1,232 @@
+/* ppo2hip — C ABI of the MI355X-native PPO2 rollout-to-update path.
+ *
+ * Drop-in boundary for pcchenxi/baselines `baselines/ppo2`: the Python host code
+ * (baselines_amd/ppo2) binds exactly these entry points with ctypes.  Every
+ * function returns 0 on success, a negative library code or a positive
+ * hipError_t otherwise; ppo2hip_last_error() describes the last failure of the
+ * calling thread.  Unless a parameter says "host", every pointer is a DEVICE
+ * pointer owned by the caller (gfx950 HBM); `stream` is a hipStream_t passed as
+ * void* and every call is asynchronous on it.  The library allocates no device
+ * memory: scratch comes in through `workspace` arguments whose size the
+ * *_workspace_bytes queries give.
+ *
+ * Citations are file:line in the reference tree (pcchenxi/baselines).
+ */
+#ifndef PPO2HIP_H
+#define PPO2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPO2HIP_VERSION 1
+
+/* library error codes (hipError_t values are positive) */
+#define PPO2HIP_OK 0
+#define PPO2HIP_EINVAL (-1)    /* bad argument (shape, null pointer, unsupported size) */
+#define PPO2HIP_ENOSPACE (-2)  /* workspace too small */
+#define PPO2HIP_EUNSUPPORTED (-3)
+
+int ppo2hip_version(void);
+const char *ppo2hip_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Rollout scans
+ * ---------------------------------------------------------------------- */
+
+/* GAE(lambda) advantages and returns over a time-major rollout.
+ * Replaces the NumPy loop of Runner.run, baselines/ppo2/common_functions.py:308-328.
+ *   rewards, values : float32 [T, E, R]     dones : uint8 [T, E] (done BEFORE step t, :258)
+ *   last_values     : float32 [E, R] (:304) last_dones : uint8 [E] (:319)
+ *   gamma           : HOST double[R] (self.gamma, :232), R <= 8      lam : scalar
+ *   advs, returns   : float32 [T, E, R] out (mb_advs :327, mb_returns :328)
+ *   advs_ori        : float32 [T, E, R] out or NULL — `returns - values` as the driver
+ *                     recomputes it in float32, baselines/ppo2/ppo2.py:92
+ * float64 carry, float32 store, returns = advs + values in float32. */
+int ppo2hip_gae_f32(const float *rewards, const float *values, const uint8_t *dones,
+                    const float *last_values, const uint8_t *last_dones, const double *gamma,
+                    double lam, int T, int E, int R, float *advs, float *returns, float *advs_ori,
+                    void *stream);
+
+/* n-step discounted returns with value bootstrap.
+ * Replaces discount_with_dones, baselines/a2c/utils.py:154-160, together with the
+ * bootstrap rule of the A2C runner, baselines/a2c/a2c.py:119-126, for all envs at once.
+ *   rewards : float32 [T, E] time-major     dones : uint8 [T, E] (done AFTER step t, a2c.py:116)
+ *   last_values : float32 [E] or NULL (NULL = plain discount_with_dones, no bootstrap)
+ *   out : float32 [T, E] */
+int ppo2hip_discount_with_dones_f32(const float *rewards, const uint8_t *dones,
+                                    const float *last_values, double gamma, int T, int E,
+                                    float *out, void *stream);
+
+/* sf01: [T, E, row] -> [E*T, row] (swap and flatten axes 0 and 1),
+ * baselines/ppo2/common_functions.py:347-352.  row_bytes = bytes of one trailing row. */
+int ppo2hip_sf01(const void *src, int T, int E, int64_t row_bytes, void *dst, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Advantage post-processing
+ * ---------------------------------------------------------------------- */
+
+/* Fork-only scalarisation of the R-channel advantage,
+ * baselines/ppo2/common_functions.py:359-401 (live terms only: the 0-weighted
+ * advs_dir and the unused grad_v are not computed).
+ *   values, advs_ori : float32 [N, R] (any row order)   max_return : HOST double[R]
+ *   workspace : device, ppo2hip_compute_advs_workspace_bytes(N, R) bytes
+ *   out : float64 [N] (the reference returns float64, :386) */
+size_t ppo2hip_compute_advs_workspace_bytes(int64_t N, int R);
+int ppo2hip_compute_advs(const float *values, const float *advs_ori, const double *max_return,
+                         int64_t N, int R, void *workspace, size_t workspace_bytes, double *out,
+                         void *stream);
+
+/* Sums for the per-minibatch normalisation of Model.train,
+ * baselines/ppo2/common_functions.py:67, for `nmb` consecutive minibatches of B rows each:
+ * stats[3*j + 0..2] = {sum a, sum a^2, count} over rows idx[j*B .. (j+1)*B) in float64
+ * (device).  `advs` is the rollout-wide array, float32 or float64 (adv_f64 != 0); rows are
+ * picked through `idx` and (T, E) as described at ppo2hip_rollout (idx NULL = rows j*B + i).
+ * workspace: ppo2hip_adv_stats_workspace_bytes(nmb) bytes. */
+size_t ppo2hip_adv_stats_workspace_bytes(int nmb);
+int ppo2hip_adv_stats(const void *advs, int adv_f64, const int32_t *idx, int64_t B, int nmb, int T,
+                      int E, void *workspace, double *stats, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Minibatch permutation (host side, bit-exact with NumPy's legacy RandomState)
+ * ---------------------------------------------------------------------- */
+
+/* MT19937 + legacy shuffle as np.random.seed / np.random.shuffle perform them at
+ * baselines/ppo2/ppo2.py:113 and :130.  All pointers here are HOST pointers. */
+typedef struct ppo2hip_rng ppo2hip_rng;
+ppo2hip_rng *ppo2hip_rng_create(uint32_t seed);
+void ppo2hip_rng_destroy(ppo2hip_rng *rng);
+void ppo2hip_rng_seed(ppo2hip_rng *rng, uint32_t seed);
+/* key: 624 words, pos in [0, 624] — the (key, pos) of np.random.get_state() */
+int ppo2hip_rng_set_state(ppo2hip_rng *rng, const uint32_t *key, int pos);
+int ppo2hip_rng_get_state(const ppo2hip_rng *rng, uint32_t *key, int *pos);
+/* in-place Fisher-Yates over inds[0..n) */
+int ppo2hip_shuffle_i64(ppo2hip_rng *rng, int64_t *inds, int64_t n);
+int ppo2hip_shuffle_i32(ppo2hip_rng *rng, int32_t *inds, int64_t n);
+
+/* ------------------------------------------------------------------------
+ * Policy description and parameter arena
+ * ---------------------------------------------------------------------- */
+
+enum { PPO2HIP_POLICY_MLP = 0, PPO2HIP_POLICY_CNN = 1, PPO2HIP_POLICY_CNN_LSTM = 2, PPO2HIP_POLICY_CNN_LNLSTM = 3 };
+enum { PPO2HIP_DIST_GAUSSIAN = 0, PPO2HIP_DIST_CATEGORICAL = 1 };
+enum { PPO2HIP_ORDER_FORK = 0, PPO2HIP_ORDER_UPSTREAM = 1 };
+
+/* Which network of the reference the arena holds.
+ *   MLP:  two separate tanh trunks (actor, value): fork MlpPolicy
+ *         baselines/ppo2/policies.py:132-181 (hidden 256,128, nvalue 5, order FORK) or the
+ *         upstream-shaped one baselines/a2c/policies.py:116-146 (hidden 64,64, nvalue 1, order UPSTREAM).
+ *   CNN*: nature_cnn + heads, baselines/ppo2/policies.py:6-130 (ob = H,W,C uint8 NHWC).
+ * Parameters live in ONE flat float32 arena in the reference's variable creation
+ * order (= checkpoint order of Model.save, baselines/ppo2/common_functions.py:115-119). */
+typedef struct ppo2hip_policy_desc {
+    int32_t kind;        /* PPO2HIP_POLICY_* */
+    int32_t dist;        /* PPO2HIP_DIST_* */
+    int32_t order;       /* PPO2HIP_ORDER_* (MLP only) */
+    int32_t ob_dim;      /* MLP: flattened observation length */
+    int32_t ob_h, ob_w, ob_c; /* CNN: NHWC image */
+    int32_t hidden1, hidden2; /* MLP trunk widths */
+    int32_t ac_dim;      /* Gaussian: action length; Categorical: number of actions */
+    int32_t nvalue;      /* value-head outputs R */
+    int32_t nlstm;       /* LSTM width (CNN_LSTM / CNN_LNLSTM) */
+} ppo2hip_policy_desc;
+
+/* Loss/optimiser variant of baselines/ppo2/common_functions.py:
+ *   upstream = 0 : live fork code :26-54 — vf_loss = mean((v-R)^2) over [B,R]; actor and value
+ *                  objectives minimised by separate, identically configured Adams; no clipping
+ *                  (vf_coef and max_grad_norm ignored, as in the fork).
+ *   upstream = 1 : the commented upstream code :30-33,:56-63 — vf_loss = .5*mean(max((v-R)^2,
+ *                  (vclipped-R)^2)); loss = pg - ent_coef*H + vf_coef*vf; clip_by_global_norm. */
+typedef struct ppo2hip_loss_desc {
+    float ent_coef;
+    float vf_coef;
+    float max_grad_norm; /* <= 0: no clipping */
+    int32_t upstream;
+} ppo2hip_loss_desc;
+
+/* number of float32 parameters, or < 0 on a bad description */
+int64_t ppo2hip_param_count(const ppo2hip_policy_desc *desc);
+/* Variable table in creation order: name (<= 31 chars), offset and shape in the arena.
+ * Returns the number of variables (writes at most `max_vars` entries), < 0 on error.
+ * HOST pointers. shapes: 4 int64 per variable, unused dims = 0. */
+int ppo2hip_param_layout(const ppo2hip_policy_desc *desc, int max_vars, char (*names)[32],
+                         int64_t *offsets, int64_t *shapes);
+
+/* ------------------------------------------------------------------------
+ * Forward, gradient and optimiser steps
+ * ---------------------------------------------------------------------- */
+
+/* Where a minibatch's rows come from.  Arrays are the time-major rollout buffers
+ * ([T, E, ...], env fastest); a minibatch row i (0 <= i < B) is flat env-major sample
+ * s = idx[i] (or s = i when idx is NULL), i.e. env = s / T, t = s % T — the indexing
+ * that `arr[mbinds]` applies to the sf01-flattened arrays at baselines/ppo2/ppo2.py:117
+ * and :134-136 — read in place at [t, env].  T = 0 means the arrays are already
+ * flat [N, ...] and s indexes them directly (what Model.train receives, :65). */
+typedef struct ppo2hip_rollout {
+    const void *obs;         /* float32 [.., ob_dim] or uint8 [.., H, W, C] */
+    const void *actions;     /* float32 [.., ac_dim] (Gaussian) or int32 [..] (Categorical) */
+    const float *returns;    /* [.., nvalue] */
+    const float *values;     /* [.., nvalue]  (OLDVPRED) */
+    const float *neglogpacs; /* [..]          (OLDNEGLOGPAC) */
+    const void *advs;        /* [..] float32, or float64 when adv_f64 != 0 (un-normalised) */
+    const uint8_t *masks;    /* [..] done-before-step flags; recurrent policies only */
+    const float *states;     /* [E, 2*nlstm] initial LSTM states of the rollout; recurrent only */
+    int32_t adv_f64;
+    int32_t T, E;
+} ppo2hip_rollout;
+
+size_t ppo2hip_forward_workspace_bytes(const ppo2hip_policy_desc *desc, int64_t B);
+/* Policy forward for Runner.run's model.step / model.value
+ * (baselines/ppo2/policies.py:161-172): obs [B, ...] -> pi [B, ac_dim] (mean or logits),
+ * vf [B, nvalue].  For recurrent policies B = nenv (one step): masks [B], states_in/out [B, 2*nlstm]. */
+int ppo2hip_policy_forward(const ppo2hip_policy_desc *desc, const float *params, const void *obs,
+                           int64_t B, const uint8_t *masks, const float *states_in,
+                           float *pi, float *vf, float *states_out, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
+/* Per-row distribution terms for Runner.run (baselines/common/distributions.py:202-205,
+ * :141-148): neglogp of `actions` under pi (and logstd from the arena). */
+int ppo2hip_neglogp(const ppo2hip_policy_desc *desc, const float *params, const float *pi,
+                    const void *actions, int64_t B, float *neglogp, void *stream);
+
+size_t ppo2hip_grad_workspace_bytes(const ppo2hip_policy_desc *desc, int64_t B);
+/* One Model.train graph evaluation up to (not including) the optimiser,
+ * baselines/ppo2/common_functions.py:26-44 + the tf.gradients of :53-54/:57:
+ * gathers the minibatch, normalises advantages with `stats` (from ppo2hip_adv_stats,
+ * possibly all-reduced across ranks; NULL = advs already normalised), runs forward, loss
+ * and backward.
+ *   grads  : float32 [P] out — sum over the B rows of d(objective)/d(param) * inv_count terms,
+ *            where the batch means of the loss use `inv_count` in place of 1/B (pass 1/B_global
+ *            on every rank of a data-parallel job and SUM-all-reduce `grads` and `losses`).
+ *   losses : float32 [8] out — {policy_loss, value_loss, policy_entropy, approxkl, clipfrac}
+ *            (loss_names order, :107) scaled the same way; [5..7] reserved.
+ * For recurrent policies B = nenvs_mb * nsteps_mb rows in env-major order and
+ * `mb_envs` (int32 [B / nsteps_mb], device) names their envs for the state gather (:136). */
+int ppo2hip_ppo_grad(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss,
+                     const float *params, const ppo2hip_rollout *rollout, const int32_t *idx,
+                     int64_t B, const int32_t *mb_envs, int32_t nsteps_mb, const double *stats,
+                     float cliprange, double inv_count, float *grads, float *losses,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* clip_by_global_norm (upstream, baselines/ppo2/common_functions.py:59-60) + Adam in the
+ * arithmetic of baselines/common/mpi_adam.py:30-35 (epsilon 1e-5 as at
+ * common_functions.py:51-52), one pass over the flat arenas.
+ *   grad_scale : multiplies grads first (1/size of MpiAdam.update, mpi_adam.py:27-28)
+ *   t          : step count AFTER this update (1 for the first)
+ *   max_grad_norm <= 0 : no clipping
+ *   scratch    : device, ppo2hip_adam_scratch_bytes(P); scratch[0] (float) = global norm after the call */
+size_t ppo2hip_adam_scratch_bytes(int64_t P);
+int ppo2hip_adam_step(float *params, const float *grads, float *m, float *v, int64_t P, double lr,
+                      int64_t t, double beta1, double beta2, double epsilon, double grad_scale,
+                      double max_grad_norm, void *scratch, void *stream);
+
+/* Plain fp32 GEMM on the MFMA path, exposed for tests: C[M,N] = A[M,K] * B[K,N] (row-major). */
+int ppo2hip_gemm_f32(const float *A, const float *B, float *C, int M, int N, int K, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPO2HIP_H */

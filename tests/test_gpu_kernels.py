@@ -1,0 +1,147 @@
+"""Parity of the HIP kernels (through the C ABI) against the CPU oracle.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import advs as oadvs
+from oracle import scan
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from baselines_amd import hip as h
+    return h
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (32, 32, 2), (64, 64, 64), (33, 17, 5), (128, 64, 16), (257, 70, 19),
+                                   (1000, 6, 64), (4096, 64, 17), (65, 64, 3000), (300, 512, 200)])
+def test_gemm_f32(hip, M, N, K):
+    rng = np.random.RandomState(M * 7 + N * 3 + K)
+    # asymmetric operands so a transposed or permuted fragment map cannot pass
+    A = (rng.randn(M, K) + np.arange(K)[None, :] * 0.01).astype(np.float32)
+    B = (rng.randn(K, N) + np.arange(N)[None, :] * 0.02).astype(np.float32)
+    C = hip.gemm(dev(A), dev(B)).cpu().numpy()
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    assert np.all(np.abs(C - ref) <= 2e-6 * scale + 1e-30)   # fp32 fma chain, K up to 3000
+
+
+CASES = ["small", "mid", "cartpole_shape", "nodone", "alldone"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gae_golden_bit_exact(hip, golden, name):
+    g = lambda k: golden["gae_%s_%s" % (name, k)]
+    advs, rets, ori = hip.gae(dev(g("rewards")), dev(g("values")), dev(g("dones")), dev(g("last_values")),
+                              dev(g("last_dones")), g("gamma"), float(g("lam")))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(hip.sf01(rets).cpu().numpy(), g("returns_flat"))
+    o_advs, o_rets = scan.gae(g("rewards"), g("values"), g("dones"), g("last_values"), g("last_dones"),
+                              g("gamma"), float(g("lam")))
+    np.testing.assert_array_equal(advs.cpu().numpy(), o_advs)
+    np.testing.assert_array_equal(ori.cpu().numpy(), o_rets - g("values"))
+
+
+@pytest.mark.parametrize("T,E,R", [(1, 1, 1), (7, 3, 1), (256, 300, 1), (37, 129, 5), (128, 1024, 1), (9, 70, 8)])
+def test_gae_random_bit_exact(hip, T, E, R):
+    rng = np.random.RandomState(T + E + R)
+    rewards = rng.randn(T, E, R).astype(np.float32)
+    values = rng.randn(T, E, R).astype(np.float32)
+    dones = rng.rand(T, E) < 0.1
+    last_values = rng.randn(E, R).astype(np.float32)
+    last_dones = rng.rand(E) < 0.3
+    gamma = np.linspace(0.99, 0.9, R)
+    advs, rets, ori = hip.gae(dev(rewards), dev(values), dev(dones), dev(last_values), dev(last_dones), gamma, 0.95)
+    o_advs, o_rets = scan.gae(rewards, values, dones, last_values, last_dones, gamma, 0.95)
+    np.testing.assert_array_equal(advs.cpu().numpy(), o_advs)
+    np.testing.assert_array_equal(rets.cpu().numpy(), o_rets)
+    np.testing.assert_array_equal(ori.cpu().numpy(), o_rets - values)
+
+
+def test_gae_empty_and_bad_shapes(hip):
+    z = torch.zeros((0, 4, 1), device="cuda")
+    advs, rets, _ = hip.gae(z, z, torch.zeros((0, 4), dtype=torch.bool, device="cuda"),
+                            torch.zeros((4, 1), device="cuda"), torch.zeros(4, dtype=torch.bool, device="cuda"), 0.99, 0.95)
+    assert advs.shape == (0, 4, 1)
+    with pytest.raises(ValueError):
+        hip.gae(torch.zeros((3, 4, 1), device="cuda"), torch.zeros((3, 4, 1), device="cuda"),
+                torch.zeros((3, 5), dtype=torch.bool, device="cuda"), torch.zeros((4, 1), device="cuda"),
+                torch.zeros(4, dtype=torch.bool, device="cuda"), 0.99, 0.95)
+    from baselines_amd._lib import Ppo2HipError
+    with pytest.raises(Ppo2HipError):   # R beyond the kernel's channel limit is refused, not truncated
+        hip.gae(torch.zeros((3, 4, 9), device="cuda"), torch.zeros((3, 4, 9), device="cuda"),
+                torch.zeros((3, 4), dtype=torch.bool, device="cuda"), torch.zeros((4, 9), device="cuda"),
+                torch.zeros(4, dtype=torch.bool, device="cuda"), 0.99, 0.95)
+
+
+def test_discount_with_dones(hip, golden):
+    rew, dn, lv = golden["a2c_rewards"], golden["a2c_dones"], golden["a2c_last_values"]   # env-major [E,T]
+    out = hip.discount_with_dones(dev(rew.T.copy()), dev(dn.T.copy()), dev(lv), 0.99).cpu().numpy().T
+    np.testing.assert_array_equal(out, golden["a2c_returns"])
+    # known-answer vector of the reference, no bootstrap
+    kat = hip.discount_with_dones(dev(np.array([[1.], [2.], [3.], [4.]], np.float32)),
+                                  dev(np.array([[0], [0], [1], [0]], np.uint8)), None, 0.9).cpu().numpy().ravel()
+    np.testing.assert_array_equal(kat, np.asarray(golden["dwd_kat"], np.float32))
+    rng = np.random.RandomState(3)
+    T, E = 37, 1500
+    rew = rng.randn(T, E).astype(np.float32)
+    dn = rng.rand(T, E) < 0.2
+    lv = rng.randn(E).astype(np.float32)
+    out = hip.discount_with_dones(dev(rew), dev(dn), dev(lv), 0.97).cpu().numpy()
+    np.testing.assert_array_equal(out.T, scan.a2c_returns(rew.T, dn.T, lv, 0.97))
+
+
+@pytest.mark.parametrize("T,E,row,dtype", [(5, 3, (), np.float32), (128, 8, (4,), np.float32), (33, 65, (17,), np.float32),
+                                           (16, 20, (5,), np.uint8), (7, 9, (), np.bool_), (4, 6, (84, 84, 4), np.uint8),
+                                           (20, 33, (63,), np.float32)])
+def test_sf01(hip, T, E, row, dtype):
+    rng = np.random.RandomState(1)
+    a = (rng.rand(T, E, *row) * 200).astype(dtype)
+    np.testing.assert_array_equal(hip.sf01(dev(a)).cpu().numpy(), scan.sf01(a))
+
+
+def _check_advs(out, ref, advs_ori):
+    """Stated tolerance of the scalarisation: the result is a float32 sum of five float32
+    products a_k * L divided by L.  The reference takes L from a float32 running mean over
+    all N rows, the kernel from a float64 tree sum, so L can differ in its last bits and every
+    product then rounds differently: agreement is to float32 rounding OF THE TERMS,
+    |diff| <= 4e-7 * sum_k |a_k| (about six float32 roundings), not of a cancelled sum."""
+    bound = 4e-7 * np.abs(advs_ori).astype(np.float64).sum(axis=1) + 1e-12
+    assert np.all(np.abs(out - ref) <= bound), float(np.max(np.abs(out - ref) / bound))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_compute_advs_golden(hip, golden, name):
+    g = lambda k: golden["gae_%s_%s" % (name, k)]
+    values, returns = g("values_flat"), g("returns_flat")
+    out = hip.compute_advs([200, 120, 0, 0, 0], dev(values), dev(returns - values)).cpu().numpy()
+    _check_advs(out, g("advs_scalar"), returns - values)
+
+
+def test_compute_advs_large(hip):
+    rng = np.random.RandomState(5)
+    N = 20000
+    values = (rng.randn(N, 5) * 10).astype(np.float32)
+    advs_ori = rng.randn(N, 5).astype(np.float32)
+    out = hip.compute_advs([200, 120, 0, 0, 0], dev(values), dev(advs_ori)).cpu().numpy()
+    _check_advs(out, oadvs.compute_advs([200, 120, 0, 0, 0], values, advs_ori), advs_ori)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_adv_stats(hip, dtype):
+    rng = np.random.RandomState(9)
+    T, E, B, nmb = 16, 40, 128, 5
+    advs = (rng.randn(T, E) * 3 + 1).astype(dtype)
+    perm = rng.permutation(T * E).astype(np.int32)
+    st = hip.adv_stats(dev(advs), dev(perm), B, nmb, T, E).cpu().numpy()
+    flat = scan.sf01(advs)
+    for j in range(nmb):
+        a = flat[perm[j * B:(j + 1) * B]].astype(np.float64)
+        np.testing.assert_allclose(st[j], [a.sum(), (a * a).sum(), B], rtol=1e-12)

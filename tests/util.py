@@ -1,0 +1,65 @@
+"""Shared helpers for the parity tests: synthetic rollouts and oracle <-> arena plumbing."""
+from collections import OrderedDict
+
+import numpy as np
+
+from oracle import tfgraph
+
+
+def make_params(shapes, seed, pi_scale=0.01, jitter=0.0):
+    rng = np.random.RandomState(seed)
+    p = tfgraph.init_params(shapes, rng, pi_scale=pi_scale)
+    if jitter:
+        for k in p:
+            p[k] = (p[k] + jitter * rng.randn(*p[k].shape)).astype(np.float32)
+    return p
+
+
+def flatten_params(params, spec):
+    """Oracle dict -> flat float32 arena in the library's variable order (names must agree)."""
+    flat = np.zeros(spec.nparams, np.float32)
+    names = [v[0] for v in spec.vars]
+    assert names == list(params.keys()), (names, list(params.keys()))
+    for name, off, shp in spec.vars:
+        a = np.asarray(params[name], np.float32)
+        assert a.size == int(np.prod(shp)), (name, a.shape, shp)
+        flat[off:off + a.size] = a.ravel()
+    return flat
+
+
+def unflatten(flat, spec, like):
+    out = OrderedDict()
+    for name, off, shp in spec.vars:
+        n = int(np.prod(shp))
+        out[name] = np.asarray(flat[off:off + n]).reshape(like[name].shape)
+    return out
+
+
+def synthetic_mlp_rollout(rng, T, E, D, A, R, gaussian, params, nlp_noise=0.3):
+    """Time-major synthetic rollout whose actions/values/neglogpacs come from `params`
+    (so ratio ~ 1 as in real PPO) with noise on the old neglogp so clipping is exercised."""
+    import torch
+    N = T * E
+    obs = rng.randn(T, E, D).astype(np.float32)
+    p = tfgraph.to_torch(params, torch.float64, requires_grad=False)
+    pi, vf = tfgraph.mlp_forward(p, torch.as_tensor(obs.reshape(N, D)).double())
+    pi, vf = pi.numpy(), vf.numpy()
+    if gaussian:
+        std = np.exp(params["logstd"].astype(np.float64))
+        actions = (pi + std * rng.randn(N, A)).astype(np.float32)
+        nlp = tfgraph.gaussian_neglogp(torch.as_tensor(pi), torch.as_tensor(params["logstd"]).double(),
+                                       torch.as_tensor(actions).double()).numpy()
+        actions = actions.reshape(T, E, A)
+    else:
+        u = rng.rand(N, A)
+        actions = np.argmax(pi - np.log(-np.log(u)), axis=1).astype(np.int32)
+        nlp = tfgraph.categorical_neglogp(torch.as_tensor(pi), torch.as_tensor(actions)).numpy()
+        actions = actions.reshape(T, E)
+    nlp = (nlp + nlp_noise * rng.randn(N)).astype(np.float32).reshape(T, E)
+    values = (vf + 0.3 * rng.randn(N, R)).astype(np.float32).reshape(T, E, R)
+    rewards = rng.randn(T, E, R).astype(np.float32)
+    dones = rng.rand(T, E) < 0.05
+    last_values = rng.randn(E, R).astype(np.float32)
+    last_dones = rng.rand(E) < 0.05
+    return dict(obs=obs, actions=actions, neglogpacs=nlp, values=values, rewards=rewards, dones=dones,
+                last_values=last_values, last_dones=last_dones)
