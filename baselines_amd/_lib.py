@@ -64,6 +64,11 @@ _SIGS = {
     "ppo2hip_rng_get_state": (c_int, [c_void_p, _P, POINTER(c_int)]),
     "ppo2hip_shuffle_i64": (c_int, [c_void_p, _P, c_int64]),
     "ppo2hip_shuffle_i32": (c_int, [c_void_p, _P, c_int64]),
+    "ppo2hip_perm_create": (c_void_p, [c_void_p, c_int64, c_int]),
+    "ppo2hip_perm_destroy": (None, [c_void_p]),
+    "ppo2hip_perm_begin": (c_int, [c_void_p, c_int, _P]),
+    "ppo2hip_perm_wait": (c_int, [c_void_p, c_int]),
+    "ppo2hip_perm_wait_all": (c_int, [c_void_p]),
     "ppo2hip_param_count": (c_int64, [POINTER(PolicyDesc)]),
     "ppo2hip_param_layout": (c_int, [POINTER(PolicyDesc), c_int, _P, _P, _P]),
     "ppo2hip_forward_workspace_bytes": (c_size_t, [POINTER(PolicyDesc), c_int64]),

@@ -4,17 +4,31 @@
 // above the bound.  This is what np.random.seed / np.random.shuffle do at
 // baselines/ppo2/ppo2.py:113 and :130 (seeded through baselines/common/misc_util.py:69-76).
 //
-// The swap targets of a block of positions are drawn first and the swaps applied second,
-// with the target cache lines prefetched: the draw order (and therefore the stream and the
-// result) is unchanged, the pass just stops stalling on one random access per element.
+// The pass is split in two stages that touch disjoint state, so they pipeline without
+// changing the stream or the result:
+//   draw  : MT19937 outputs (generated 624 at a time, tempering vectorised) -> accepted swap
+//           targets j_i, compacted without a data-dependent branch (the accept test only
+//           steers an index increment);
+//   swap  : x[i] <-> x[j_i] with the target cache lines prefetched.
+// ppo2hip_shuffle_* runs both stages inline; the ppo2hip_perm_* pipeline runs them on two
+// worker threads and produces the cumulative shuffles of all epochs of an update ahead of
+// the GPU, so index generation overlaps the kernels of the previous epoch.
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+#if defined(__AVX2__)
+#include <immintrin.h>
+#endif
 
 #include "common.hpp"
 
 struct ppo2hip_rng {
     uint32_t mt[624];
-    int pos;
+    int pos;           // NumPy's position: next output is tempered mt[pos]; 624 = regenerate first
 };
 
 namespace {
@@ -27,22 +41,23 @@ void seed_state(ppo2hip_rng *s, uint32_t seed) {
     s->pos = N;
 }
 
-void regenerate(ppo2hip_rng *s) {
-    uint32_t *mt = s->mt;
-    int k = 0;
-    auto twist = [](uint32_t u, uint32_t v) {
-        uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
-        return (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
-    };
-    for (; k < N - M; k++) mt[k] = mt[k + M] ^ twist(mt[k], mt[k + 1]);
-    for (; k < N - 1; k++) mt[k] = mt[k + (M - N)] ^ twist(mt[k], mt[k + 1]);
-    mt[N - 1] = mt[M - 1] ^ twist(mt[N - 1], mt[0]);
-    s->pos = 0;
+inline uint32_t twist(uint32_t u, uint32_t v) {
+    const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return (y >> 1) ^ ((0u - (v & 1u)) & 0x9908b0dfu);
 }
 
-inline uint32_t next_u32(ppo2hip_rng *s) {
-    if (s->pos >= N) regenerate(s);
-    uint32_t y = s->mt[s->pos++];
+void regenerate(uint32_t *__restrict mt) {
+    int k = 0;
+    // 0..226 read only not-yet-rewritten words: independent iterations
+#pragma clang loop vectorize(assume_safety)
+    for (k = 0; k < N - M; k++) mt[k] = mt[k + M] ^ twist(mt[k], mt[k + 1]);
+    // 227..622 read words rewritten 227 iterations earlier: safe for any vector width <= 227
+#pragma clang loop vectorize(assume_safety)
+    for (k = N - M; k < N - 1; k++) mt[k] = mt[k + (M - N)] ^ twist(mt[k], mt[k + 1]);
+    mt[N - 1] = mt[M - 1] ^ twist(mt[N - 1], mt[0]);
+}
+
+inline uint32_t temper(uint32_t y) {
     y ^= y >> 11;
     y ^= (y << 7) & 0x9d2c5680u;
     y ^= (y << 15) & 0xefc60000u;
@@ -50,18 +65,101 @@ inline uint32_t next_u32(ppo2hip_rng *s) {
     return y;
 }
 
-inline uint32_t bounded(ppo2hip_rng *s, uint32_t max) {
-    if (max == 0) return 0;
-    uint32_t mask = max;
-    mask |= mask >> 1;
-    mask |= mask >> 2;
-    mask |= mask >> 4;
-    mask |= mask >> 8;
-    mask |= mask >> 16;
-    uint32_t v;
-    while ((v = next_u32(s) & mask) > max) {
+// Buffered view of the stream: tempered outputs of the current 624-word block.
+struct Stream {
+    ppo2hip_rng *s;
+    uint32_t out[N];
+    explicit Stream(ppo2hip_rng *r) : s(r) {
+        if (s->pos < N) fill();
     }
-    return v;
+    void fill() {
+        for (int i = 0; i < N; i++) out[i] = temper(s->mt[i]);
+    }
+    void refill() {
+        regenerate(s->mt);
+        s->pos = 0;
+        fill();
+    }
+};
+
+#if defined(__AVX2__)
+// lane permutation that packs the lanes selected by an 8-bit mask to the front
+struct PackLut {
+    alignas(32) uint32_t idx[256][8];
+    PackLut() {
+        for (int m = 0; m < 256; m++) {
+            int w = 0;
+            for (int b = 0; b < 8; b++)
+                if (m & (1 << b)) idx[m][w++] = b;
+            for (; w < 8; w++) idx[m][w] = 0;
+        }
+    }
+};
+static const PackLut g_pack;
+#endif
+
+// Accepted swap targets for positions hi, hi-1, ..., lo (lo >= 1), written to js[0 .. hi-lo]
+// (up to 8 words of scratch may be written past that).  Eight candidates are classified at
+// once: a masked value <= i-7 is accepted and one > i is rejected whatever the seven
+// decisions before it were, so unless a value falls in the 7-wide window between (about
+// 8 / 2^k of the blocks) the block is compacted with one vector permute; otherwise, and
+// near buffer or mask-range ends, candidates go through the scalar loop, in which the
+// accept test only steers an index increment (no data-dependent branch).
+void draw_targets(Stream &st, int64_t hi, int64_t lo, uint32_t *js) {
+    ppo2hip_rng *s = st.s;
+    int64_t i = hi;
+    int64_t w = 0;
+    while (i >= lo) {
+        if (s->pos >= N) st.refill();
+        uint32_t mask = (uint32_t)i;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        // positions that share this mask: i down to max(lo, (mask >> 1) + 1)
+        const int64_t lim_mask = (int64_t)(mask >> 1) + 1;
+        const int64_t stop = lim_mask > lo ? lim_mask : lo;
+        int p = s->pos;
+#if defined(__AVX2__)
+        if (mask <= 0x7fffffffu) {
+            const __m256i vmask = _mm256_set1_epi32((int)mask);
+            while (p + 8 <= N && i - 7 >= stop) {
+                const __m256i v = _mm256_and_si256(_mm256_loadu_si256((const __m256i *)(st.out + p)), vmask);
+                const __m256i gt_lo = _mm256_cmpgt_epi32(v, _mm256_set1_epi32((int)(i - 7)));   // v > i-7
+                const __m256i gt_hi = _mm256_cmpgt_epi32(v, _mm256_set1_epi32((int)i));         // v > i
+                const int m_gt_lo = _mm256_movemask_ps(_mm256_castsi256_ps(gt_lo));
+                const int m_gt_hi = _mm256_movemask_ps(_mm256_castsi256_ps(gt_hi));
+                if (m_gt_lo != m_gt_hi) break;            // some value in (i-7, i]: decide serially
+                const int acc = (~m_gt_lo) & 0xff;
+                const __m256i packed = _mm256_permutevar8x32_epi32(v, _mm256_load_si256((const __m256i *)g_pack.idx[acc]));
+                _mm256_storeu_si256((__m256i *)(js + w), packed);
+                const int na = __builtin_popcount(acc);
+                w += na;
+                i -= na;
+                p += 8;
+            }
+        }
+#endif
+        // scalar: at most 8 candidates after a vector bail-out, everything near the ends
+        int budget = 8;
+        while (p < N && i >= stop && budget-- > 0) {
+            const uint32_t v = st.out[p++] & mask;
+            js[w] = v;
+            const int64_t acc = (int64_t)(v <= (uint32_t)i);
+            w += acc;
+            i -= acc;
+        }
+        s->pos = p;
+    }
+}
+
+template <class I>
+void apply_swaps(I *x, int64_t hi, const uint32_t *js, int64_t cnt) {
+    constexpr int AHEAD = 24;
+    for (int64_t k = 0; k < cnt; k++) {
+        if (k + AHEAD < cnt) __builtin_prefetch(&x[js[k + AHEAD]], 1, 1);
+        const int64_t a = hi - k;
+        const I tmp = x[a];
+        x[a] = x[js[k]];
+        x[js[k]] = tmp;
+    }
 }
 
 template <class I>
@@ -74,19 +172,14 @@ int shuffle_impl(ppo2hip_rng *rng, I *x, int64_t n) {
         ppo2hip::set_error("shuffle: n=%lld outside [0, 2^32)", (long long)n);
         return PPO2HIP_EINVAL;
     }
-    constexpr int BLK = 2048, AHEAD = 24;
-    uint32_t js[BLK];
+    constexpr int64_t BLK = 4096;
+    std::vector<uint32_t> js(BLK + 16);
+    Stream st(rng);
     int64_t i = n - 1;
     while (i >= 1) {
-        const int cnt = (int)(i < BLK ? i : BLK);
-        for (int k = 0; k < cnt; k++) js[k] = bounded(rng, (uint32_t)(i - k));
-        for (int k = 0; k < cnt; k++) {
-            if (k + AHEAD < cnt) __builtin_prefetch(&x[js[k + AHEAD]], 1, 1);
-            const int64_t a = i - k;
-            const I tmp = x[a];
-            x[a] = x[js[k]];
-            x[js[k]] = tmp;
-        }
+        const int64_t cnt = i < BLK ? i : BLK;
+        draw_targets(st, i, i - cnt + 1, js.data());
+        apply_swaps(x, i, js.data(), cnt);
         i -= cnt;
     }
     return PPO2HIP_OK;
@@ -123,3 +216,163 @@ extern "C" int ppo2hip_rng_get_state(const ppo2hip_rng *rng, uint32_t *key, int 
 }
 extern "C" int ppo2hip_shuffle_i64(ppo2hip_rng *rng, int64_t *inds, int64_t n) { return shuffle_impl(rng, inds, n); }
 extern "C" int ppo2hip_shuffle_i32(ppo2hip_rng *rng, int32_t *inds, int64_t n) { return shuffle_impl(rng, inds, n); }
+
+// ---------------------------------------------------------------------------------------
+// Two-stage pipeline over all epochs of an update
+// ---------------------------------------------------------------------------------------
+struct ppo2hip_perm {
+    ppo2hip_rng *rng = nullptr;
+    int64_t n = 0;
+    int max_epochs = 0;
+    std::vector<uint32_t> js;          // [max_epochs][n-1] swap targets in draw order
+    std::vector<int32_t> x;            // running permutation (epoch e shuffles epoch e-1's order)
+    std::vector<int32_t *> out;        // caller's per-epoch destinations
+    int nepochs = 0;
+    std::atomic<int64_t> drawn{0};     // swap targets published so far (this job)
+    std::atomic<int> epochs_done{0};
+    std::atomic<bool> draw_done{true};
+    uint64_t job = 0, job_draw = 0, job_swap = 0;
+    bool quit = false;
+    std::mutex mu;
+    std::condition_variable cv_start, cv_done;
+    std::thread t_draw, t_swap;
+
+    void draw_loop() {
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_start.wait(lk, [&] { return quit || job_draw != job; });
+                if (quit) return;
+                job_draw = job;
+            }
+            const int64_t per = n - 1;
+            Stream st(rng);
+            constexpr int64_t BLK = 8192;
+            for (int e = 0; e < nepochs; e++) {
+                int64_t i = n - 1;
+                uint32_t *dst = js.data() + (size_t)e * per;
+                while (i >= 1) {
+                    const int64_t cnt = i < BLK ? i : BLK;
+                    draw_targets(st, i, i - cnt + 1, dst + (per - i));
+                    i -= cnt;
+                    drawn.store((int64_t)e * per + (per - i), std::memory_order_release);
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                draw_done.store(true);
+            }
+            cv_done.notify_all();
+        }
+    }
+
+    void swap_loop() {
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_start.wait(lk, [&] { return quit || job_swap != job; });
+                if (quit) return;
+                job_swap = job;
+            }
+            const int64_t per = n - 1;
+            for (int64_t k = 0; k < n; k++) x[k] = (int32_t)k;
+            for (int e = 0; e < nepochs; e++) {
+                int64_t done = 0;
+                const uint32_t *src = js.data() + (size_t)e * per;
+                while (done < per) {
+                    int64_t avail = drawn.load(std::memory_order_acquire) - (int64_t)e * per;
+                    if (avail > per) avail = per;
+                    if (avail <= done) {
+                        std::this_thread::yield();
+                        continue;
+                    }
+                    apply_swaps(x.data(), (n - 1) - done, src + done, avail - done);
+                    done = avail;
+                }
+                std::memcpy(out[e], x.data(), (size_t)n * sizeof(int32_t));
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    epochs_done.store(e + 1);
+                }
+                cv_done.notify_all();
+            }
+        }
+    }
+};
+
+extern "C" ppo2hip_perm *ppo2hip_perm_create(ppo2hip_rng *rng, int64_t n, int max_epochs) {
+    if (!rng || n < 1 || n > 0x7fffffffll || max_epochs < 1 || max_epochs > 1024) {
+        ppo2hip::set_error("perm_create: bad argument (n=%lld, max_epochs=%d)", (long long)n, max_epochs);
+        return nullptr;
+    }
+    ppo2hip_perm *p = new ppo2hip_perm;
+    p->rng = rng;
+    p->n = n;
+    p->max_epochs = max_epochs;
+    p->js.resize((size_t)max_epochs * (size_t)(n > 1 ? n - 1 : 1) + 16);
+    p->x.resize((size_t)n);
+    p->out.resize(max_epochs);
+    p->t_draw = std::thread([p] { p->draw_loop(); });
+    p->t_swap = std::thread([p] { p->swap_loop(); });
+    return p;
+}
+
+extern "C" int ppo2hip_perm_wait_all(ppo2hip_perm *p);
+
+extern "C" void ppo2hip_perm_destroy(ppo2hip_perm *p) {
+    if (!p) return;
+    ppo2hip_perm_wait_all(p);
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->quit = true;
+    }
+    p->cv_start.notify_all();
+    p->t_draw.join();
+    p->t_swap.join();
+    delete p;
+}
+
+extern "C" int ppo2hip_perm_begin(ppo2hip_perm *p, int nepochs, int32_t *const *out) {
+    if (!p || !out || nepochs < 1 || nepochs > p->max_epochs) {
+        ppo2hip::set_error("perm_begin: bad argument");
+        return PPO2HIP_EINVAL;
+    }
+    for (int e = 0; e < nepochs; e++)
+        if (!out[e]) {
+            ppo2hip::set_error("perm_begin: null destination for epoch %d", e);
+            return PPO2HIP_EINVAL;
+        }
+    int rc = ppo2hip_perm_wait_all(p);   // one job at a time: the previous one must have drained
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->nepochs = nepochs;
+        for (int e = 0; e < nepochs; e++) p->out[e] = out[e];
+        p->drawn.store(0);
+        p->epochs_done.store(0);
+        p->draw_done.store(false);
+        p->job++;
+    }
+    p->cv_start.notify_all();
+    return PPO2HIP_OK;
+}
+
+extern "C" int ppo2hip_perm_wait(ppo2hip_perm *p, int epoch) {
+    if (!p || epoch < 0 || epoch >= p->nepochs) {
+        ppo2hip::set_error("perm_wait: bad epoch");
+        return PPO2HIP_EINVAL;
+    }
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv_done.wait(lk, [&] { return p->epochs_done.load() > epoch; });
+    return PPO2HIP_OK;
+}
+
+extern "C" int ppo2hip_perm_wait_all(ppo2hip_perm *p) {
+    if (!p) {
+        ppo2hip::set_error("perm_wait_all: null handle");
+        return PPO2HIP_EINVAL;
+    }
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv_done.wait(lk, [&] { return p->draw_done.load() && p->epochs_done.load() >= p->nepochs; });
+    return PPO2HIP_OK;
+}

@@ -1,0 +1,90 @@
+"""Small in-process vectorised environments with the VecEnv interface of
+baselines/common/vec_env/__init__.py:22-88 (num_envs, observation_space, action_space,
+reset, step, close), used by the tests, the smoke run and the CPU-runnable CartPole
+configuration.  gym is not a dependency, so CartPole's dynamics are written out here.
+"""
+import numpy as np
+
+from .spaces import Box, Discrete
+
+
+class CartPoleVecEnv:
+    """`nenvs` independent cart-poles (classic control equations, Euler integration,
+    episode ends at |x| > 2.4, |theta| > 12 deg or 200 steps), auto-resetting on done."""
+
+    def __init__(self, nenvs, seed=0, reward_columns=None):
+        self.num_envs = nenvs
+        self.observation_space = Box(-np.inf, np.inf, shape=(4,), dtype=np.float32)
+        self.action_space = Discrete(2)
+        self.rng = np.random.RandomState(seed)
+        self.reward_columns = reward_columns
+        self.state = np.zeros((nenvs, 4))
+        self.steps = np.zeros(nenvs, np.int64)
+        self.ep_ret = np.zeros(nenvs)
+
+    def _reset_some(self, mask):
+        n = int(mask.sum())
+        self.state[mask] = self.rng.uniform(-0.05, 0.05, size=(n, 4))
+        self.steps[mask] = 0
+        self.ep_ret[mask] = 0.0
+
+    def reset(self):
+        self._reset_some(np.ones(self.num_envs, bool))
+        return self.state.astype(np.float32)
+
+    def step(self, actions):
+        g, mc, mp, l, fm, tau = 9.8, 1.0, 0.1, 0.5, 10.0, 0.02
+        x, xd, th, thd = self.state.T
+        force = np.where(np.asarray(actions).ravel() == 1, fm, -fm)
+        ct, st = np.cos(th), np.sin(th)
+        temp = (force + mp * l * thd ** 2 * st) / (mc + mp)
+        thacc = (g * st - ct * temp) / (l * (4.0 / 3.0 - mp * ct ** 2 / (mc + mp)))
+        xacc = temp - mp * l * thacc * ct / (mc + mp)
+        self.state = np.stack([x + tau * xd, xd + tau * xacc, th + tau * thd, thd + tau * thacc], axis=1)
+        self.steps += 1
+        self.ep_ret += 1.0
+        dones = (np.abs(self.state[:, 0]) > 2.4) | (np.abs(self.state[:, 2]) > 12 * np.pi / 180) | (self.steps >= 200)
+        infos = [{} for _ in range(self.num_envs)]
+        for i in np.nonzero(dones)[0]:
+            infos[i] = {"episode": {"r": np.array([self.ep_ret[i]]), "l": int(self.steps[i])}}
+        self._reset_some(dones)
+        rews = np.ones(self.num_envs, np.float32)
+        if self.reward_columns:
+            rews = np.repeat(rews[:, None], self.reward_columns, axis=1)
+        return self.state.astype(np.float32), rews, dones, infos
+
+    def close(self):
+        pass
+
+
+class SyntheticVecEnv:
+    """Random observations / rewards / dones of a given shape — a stand-in for MuJoCo- or
+    Atari-shaped environments when only the update path is under test.  With
+    ``reward_columns = R + 1`` it returns the fork's reward layout (R channels + total score,
+    baselines/ppo2/common_functions.py:262)."""
+
+    def __init__(self, nenvs, ob_shape, action_space, reward_columns=None, done_p=0.01, ob_dtype=np.float32, seed=0):
+        self.num_envs = nenvs
+        self.ob_shape, self.ob_dtype = tuple(ob_shape), np.dtype(ob_dtype)
+        lo, hi = (0, 255) if self.ob_dtype == np.uint8 else (-np.inf, np.inf)
+        self.observation_space = Box(lo, hi, shape=self.ob_shape, dtype=self.ob_dtype)
+        self.action_space = action_space
+        self.reward_columns, self.done_p = reward_columns, done_p
+        self.rng = np.random.RandomState(seed)
+
+    def _obs(self):
+        if self.ob_dtype == np.uint8:
+            return self.rng.randint(0, 256, size=(self.num_envs,) + self.ob_shape).astype(np.uint8)
+        return self.rng.randn(self.num_envs, *self.ob_shape).astype(np.float32)
+
+    def reset(self):
+        return self._obs()
+
+    def step(self, actions):
+        shape = (self.num_envs, self.reward_columns) if self.reward_columns else (self.num_envs,)
+        rews = self.rng.randn(*shape).astype(np.float32)
+        dones = self.rng.rand(self.num_envs) < self.done_p
+        return self._obs(), rews, dones, [{} for _ in range(self.num_envs)]
+
+    def close(self):
+        pass

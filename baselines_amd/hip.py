@@ -203,6 +203,35 @@ class LegacyShuffler:
         return inds
 
 
+class PermPipeline:
+    """All epochs' index lists of an update, generated in the background (two C++ worker
+    threads) into pinned host buffers, from a LegacyShuffler's stream."""
+
+    def __init__(self, shuffler, n, max_epochs, pinned=True):
+        self.shuffler, self.n, self.max_epochs = shuffler, int(n), int(max_epochs)
+        self._h = lib.ppo2hip_perm_create(shuffler._h, self.n, self.max_epochs)
+        if not self._h:
+            check(_lib.EINVAL, "perm_create")
+        pin = bool(pinned and torch.cuda.is_available())
+        self.bufs = [torch.empty(self.n, dtype=torch.int32, pin_memory=pin) for _ in range(self.max_epochs)]
+        self._ptrs = (ctypes.c_void_p * self.max_epochs)(*[b.data_ptr() for b in self.bufs])
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.ppo2hip_perm_destroy(h)
+
+    def begin(self, nepochs):
+        check(lib.ppo2hip_perm_begin(self._h, int(nepochs), self._ptrs), "perm_begin")
+
+    def wait(self, epoch):
+        check(lib.ppo2hip_perm_wait(self._h, int(epoch)), "perm_wait")
+        return self.bufs[epoch]
+
+    def wait_all(self):
+        check(lib.ppo2hip_perm_wait_all(self._h), "perm_wait_all")
+
+
 # --------------------------------------------------------------------------------------
 # policy arena, forward, gradient, optimiser
 # --------------------------------------------------------------------------------------

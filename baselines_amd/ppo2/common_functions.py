@@ -1,0 +1,419 @@
+"""``Model`` and ``Runner`` of the fork's PPO2 (baselines/ppo2/common_functions.py) on the
+MI355X-native kernels, plus ``sf01``, ``constfn``, ``compute_advs`` and ``REWARD_NUM``.
+
+Everything numerical runs in libppo2hip: GAE, flatten, advantage scalarisation and
+normalisation, gather, forward/loss/backward, clip + Adam.  This module keeps the
+reference's call signatures, moves host arrays to HBM and back, and adds a device-resident
+fast path (``Model.train_on_rollout``) that ``learn`` uses to run all epochs of an update
+without a host round trip per minibatch.
+"""
+import time
+
+import numpy as np
+import torch
+
+from .. import _lib, hip
+
+REWARD_NUM = 5   # baselines/ppo2/common_functions.py:6
+
+
+class DeviceRollout:
+    """Time-major rollout buffers in HBM ([T, E, ...], env fastest) as the kernels read them."""
+
+    def __init__(self, T, E, obs, actions, rewards, values, neglogpacs, dones, last_values, last_dones,
+                 states=None):
+        self.T, self.E = T, E
+        self.obs, self.actions, self.rewards, self.values = obs, actions, rewards, values
+        self.neglogpacs, self.dones, self.last_values, self.last_dones = neglogpacs, dones, last_values, last_dones
+        self.states = states
+        self.advs_gae = self.returns = self.advs_ori = None
+        self.advs = None   # scalar advantage fed to the update: float32 or float64 [T, E]
+
+
+class Model(object):
+    """baselines/ppo2/common_functions.py:7-220.
+
+    Build-only keyword arguments (reference-literal defaults):
+      upstream_loss : None -> fork loss/optimiser for fork-signature policies, the upstream
+                      variant (value clipping, .5 factor, joint loss, clip_by_global_norm, and
+                      ``advs = returns - values`` inside ``train``) for upstream-signature ones.
+      reward_num    : value-head outputs for fork-signature policies (default REWARD_NUM).
+      comm          : a ``DataParallel`` context; gradients are all-reduced before Adam.
+    """
+
+    def __init__(self, *, policy, ob_space, ac_space, nbatch_act, nbatch_train, nsteps, ent_coef, vf_coef,
+                 max_grad_norm, model_name="model", lr=None, need_summary=False, upstream_loss=None,
+                 reward_num=None, comm=None):
+        sess = None
+        self.signature = getattr(policy, "signature", "fork")
+        if self.signature == "fork":
+            rn = REWARD_NUM if reward_num is None else reward_num
+            act_model = policy(sess, ob_space, ac_space, rn, reuse=False, model_name=model_name)
+            train_model = policy(sess, ob_space, ac_space, rn, reuse=True, model_name=model_name)
+        else:
+            act_model = policy(sess, ob_space, ac_space, nbatch_act, 1, reuse=False)
+            train_model = policy(sess, ob_space, ac_space, nbatch_train, nsteps, reuse=True)
+        self.upstream_loss = (self.signature != "fork") if upstream_loss is None else bool(upstream_loss)
+        self.spec = train_model.spec
+        self.arena = train_model.arena
+        self.device = self.arena.theta.device
+        self.comm = comm
+        self.nsteps = nsteps
+        self.nbatch_train = nbatch_train
+        self.loss_desc = _lib.LossDesc(float(ent_coef), float(vf_coef), float(max_grad_norm or 0.0),
+                                       1 if self.upstream_loss else 0)
+        self.max_grad_norm = float(max_grad_norm or 0.0) if self.upstream_loss else 0.0
+        P = self.spec.nparams
+        self.grads = torch.zeros(P, dtype=torch.float32, device=self.device)
+        self.adam_m = torch.zeros(P, dtype=torch.float32, device=self.device)
+        self.adam_v = torch.zeros(P, dtype=torch.float32, device=self.device)
+        self.adam_t = 0
+        self._adam_scratch = hip.adam_scratch(P, self.device)
+        self._ws = None
+        self._ws_rows = 0
+        self._stat_ws = None
+        self._losses = torch.zeros((1, 8), dtype=torch.float32, device=self.device)
+        if comm is not None:
+            comm.bcast_(self.arena.theta)          # MpiAdam.sync, baselines/common/mpi_adam.py:37-40
+
+        self.loss_names = ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
+        self.train_model = train_model
+        self.act_model = act_model
+        self.step = act_model.step
+        if hasattr(act_model, "step_max"):
+            self.step_max = act_model.step_max
+        self.value = act_model.value
+        self.initial_state = act_model.initial_state
+        self.train = self._train_fork if self.signature == "fork" else self._train_upstream
+        if need_summary:
+            self.summaries = []
+            self.write_summary = lambda tag, value, step: self.summaries.append((tag, float(value), step))
+            self.log_histogram = lambda tag, values, step, bins=1000: None
+
+    # ------------------------------------------------------------------ helpers
+    def _workspace(self, B):
+        if self._ws is None or self._ws_rows < B:
+            self._ws = torch.empty(self.spec.grad_workspace_bytes(B), dtype=torch.uint8, device=self.device)
+            self._ws_rows = B
+        return self._ws
+
+    def _stats_workspace(self, nmb):
+        need = int(_lib.lib.ppo2hip_adv_stats_workspace_bytes(nmb))
+        if self._stat_ws is None or self._stat_ws.numel() < need:
+            self._stat_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._stat_ws
+
+    def _apply(self, lr):
+        """All-reduce (data parallel) + clip + Adam on the gradient arena."""
+        scale = 1.0
+        if self.comm is not None and self.comm.size > 1:
+            self.comm.allreduce_sum_(self.grads)
+            scale = self.comm.grad_scale
+        self.adam_t += 1
+        hip.adam_step(self.arena.theta, self.grads, self.adam_m, self.adam_v, lr, self.adam_t, self._adam_scratch,
+                      max_grad_norm=self.max_grad_norm, grad_scale=scale)
+
+    def _up(self, a, dtype):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self.device)
+
+    # ------------------------------------------------------------------ Model.train
+    def _train_fork(self, lr, cliprange, obs, returns, masks, actions, values, advs, neglogpacs,
+                    actions_suggest_list=[], advs_suggest_list=[], states=None):   # noqa: B006 (reference signature)
+        """baselines/ppo2/common_functions.py:65-106 (the suggestion lists are dead code there)."""
+        return self._train_host(lr, cliprange, obs, returns, masks, actions, values, advs, neglogpacs, states)
+
+    def _train_upstream(self, lr, cliprange, obs, returns, masks, actions, values, neglogpacs, states=None):
+        """Upstream arity: ``advs = returns - values`` inside train."""
+        returns = np.asarray(returns, np.float32)
+        values = np.asarray(values, np.float32)
+        advs = (returns - values).reshape(len(returns), -1)[:, 0]
+        return self._train_host(lr, cliprange, obs, returns, masks, actions, values, advs, neglogpacs, states)
+
+    def _train_host(self, lr, cliprange, obs, returns, masks, actions, values, advs, neglogpacs, states):
+        spec = self.spec
+        B = len(obs)
+        advs = np.asarray(advs)
+        d_adv = self._up(advs, np.float64 if advs.dtype == np.float64 else np.float32)
+        d_obs = self._up(np.asarray(obs).reshape((B,) + tuple(spec.ob_shape())),
+                         np.float32 if spec.kind == _lib.POLICY_MLP else np.uint8)
+        d_act = self._up(actions, np.float32 if spec.gaussian else np.int32)
+        d_ret = self._up(np.asarray(returns).reshape(B, spec.nvalue), np.float32)
+        d_val = self._up(np.asarray(values).reshape(B, spec.nvalue), np.float32)
+        d_nlp = self._up(neglogpacs, np.float32)
+        d_masks = d_states = mb_envs = None
+        nsteps_mb = 0
+        if states is not None:
+            d_masks = self._up(np.asarray(masks).astype(np.uint8), np.uint8)
+            d_states = self._up(states, np.float32)
+            nenv_mb = d_states.shape[0]
+            nsteps_mb = B // nenv_mb
+            mb_envs = torch.arange(nenv_mb, dtype=torch.int32, device=self.device)
+        ro = hip.RolloutRef(spec, d_obs, d_act, d_ret, d_val, d_nlp, d_adv, 0, 0, d_masks, d_states)
+        stats = hip.adv_stats(d_adv, None, B, 1, 0, 0, self._stats_workspace(1))
+        inv_count = 1.0 / B
+        if self.comm is not None and self.comm.size > 1 and self.comm.mode == "global":
+            self.comm.allreduce_sum_(stats)
+            inv_count = 1.0 / float(stats[0, 2].item())
+        hip.ppo_grad(spec, self.loss_desc, self.arena.theta, ro, None, B, stats, cliprange, inv_count, self.grads,
+                     self._losses[0], self._workspace(B), mb_envs, nsteps_mb)
+        self._apply(lr)
+        out = self._losses[0, :5].clone()
+        if self.comm is not None and self.comm.size > 1:
+            self.comm.allreduce_sum_(out)
+            if self.comm.mode != "global":
+                out /= self.comm.size
+        return [np.float32(x) for x in out.cpu().numpy()]
+
+    # ------------------------------------------------------------------ device fast path
+    def seed_shuffle(self, seed):
+        """Give the model its own MT19937 stream for minibatch shuffles (same stream as
+        ``np.random.seed(seed)``); without it the global ``np.random`` stream is used, as in
+        the reference."""
+        self._shuffler = hip.LegacyShuffler(seed)
+        self._own_stream = True
+
+    def _index_pipeline(self, N, noptepochs):
+        key = (N, noptepochs)
+        if getattr(self, "_pp_key", None) != key:
+            if not hasattr(self, "_shuffler"):
+                self._shuffler = hip.LegacyShuffler(0)
+                self._own_stream = False
+            self._pp = hip.PermPipeline(self._shuffler, N, noptepochs)
+            self._pp_key = key
+            self._idx_dev = [torch.empty(N, dtype=torch.int32, device=self.device) for _ in range(noptepochs)]
+            self._idx_free = [None] * noptepochs      # main-stream event: kernels reading _idx_dev[e] done
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._copy_last = None
+        return self._pp
+
+    def train_on_rollout(self, lr, cliprange, ro, noptepochs, nbatch_train):
+        """All epochs x minibatches of one update from device-resident rollout buffers.
+
+        Index generation follows baselines/ppo2/ppo2.py:110-116 (``inds`` shuffled in place
+        every epoch) or :124-136 for recurrent policies (env sequences), drawn from the
+        global ``np.random`` stream (or the model's own after ``seed_shuffle``).  The index
+        lists are produced by the C++ pipeline while the GPU works on earlier epochs and
+        reach HBM on a side stream.  Nothing here waits for the GPU: the result is a device
+        tensor holding the mean of the per-minibatch loss rows (:139).
+        """
+        spec = self.spec
+        T, E = ro.T, ro.E
+        N = T * E
+        main = torch.cuda.current_stream()
+        rref = hip.RolloutRef(spec, ro.obs, ro.actions, ro.returns, ro.values, ro.neglogpacs, ro.advs, T, E,
+                              ro.dones if spec.recurrent else None, ro.states)
+        comm = self.comm if (self.comm is not None and self.comm.size > 1) else None
+        if not spec.recurrent:
+            if N % nbatch_train != 0:
+                raise AssertionError("nbatch %% nbatch_train != 0")   # baselines/ppo2/ppo2.py:74
+            nmb = N // nbatch_train
+            pp = self._index_pipeline(N, noptepochs)
+            if self._copy_last is not None:
+                self._copy_last.synchronize()      # pinned index buffers of the previous update are free
+            if not self._own_stream:
+                self._shuffler.adopt_numpy()
+            pp.begin(noptepochs)
+        else:
+            envsperbatch = nbatch_train // T
+            if envsperbatch < 1 or E % envsperbatch != 0:
+                raise AssertionError("nenvs must be a multiple of the envs per minibatch")
+            nmb = E // envsperbatch
+            envinds = np.arange(E, dtype=np.int32)
+            tgrid = np.arange(T, dtype=np.int32)[None, :]
+        total = nmb * noptepochs
+        if self._losses.shape[0] < total:
+            self._losses = torch.zeros((total, 8), dtype=torch.float32, device=self.device)
+        ws = self._workspace(nbatch_train)
+        stat_ws = self._stats_workspace(nmb)
+        row = 0
+        for e in range(noptepochs):
+            if not spec.recurrent:
+                host_idx = pp.wait(e)
+                d_idx = self._idx_dev[e]
+                with torch.cuda.stream(self._copy_stream):
+                    if self._idx_free[e] is not None:
+                        self._copy_stream.wait_event(self._idx_free[e])
+                    d_idx.copy_(host_idx, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy_stream)
+                self._copy_last = ev
+                main.wait_event(ev)
+                d_envs = None
+            else:
+                np.random.shuffle(envinds)                       # :130
+                flat = (envinds[:, None].astype(np.int64) * T + tgrid).astype(np.int32).ravel()   # :134
+                d_idx = torch.from_numpy(flat).to(self.device)
+                d_envs = torch.from_numpy(envinds.copy()).to(self.device)
+            stats = hip.adv_stats(ro.advs, d_idx, nbatch_train, nmb, T, E, stat_ws)
+            for j in range(nmb):
+                lo = j * nbatch_train
+                mb_envs = d_envs[j * envsperbatch:(j + 1) * envsperbatch] if spec.recurrent else None
+                hip.ppo_grad(spec, self.loss_desc, self.arena.theta, rref, d_idx[lo:lo + nbatch_train], nbatch_train,
+                             stats[j], cliprange, 1.0 / nbatch_train, self.grads, self._losses[row], ws, mb_envs,
+                             T if spec.recurrent else 0)
+                self._apply(lr)
+                row += 1
+            if not spec.recurrent:
+                done = torch.cuda.Event()
+                done.record(main)
+                self._idx_free[e] = done
+        if not spec.recurrent:
+            pp.wait_all()
+            if not self._own_stream:
+                self._shuffler.release_numpy()
+        out = self._losses[:total, :5].double().sum(dim=0) / total
+        if comm is not None:
+            comm.allreduce_sum_(out)
+            out = out / comm.size
+        return out.float()
+
+    # ------------------------------------------------------------------ misc surface
+    def get_values(self, obs):
+        return self.train_model.value(obs)
+
+    def get_actions_dist(self, obs):
+        """[mode actions, std] (baselines/ppo2/common_functions.py:112-113)."""
+        return [self.train_model.sample(obs), self.train_model.std]
+
+    def save(self, save_path, save_path_base=None):
+        """joblib list of arrays in variable creation order, written twice
+        (baselines/ppo2/common_functions.py:115-119)."""
+        import joblib
+        ps = self.arena.get_list()
+        joblib.dump(ps, save_path)
+        if save_path_base is not None:
+            joblib.dump(ps, save_path_base)
+
+    def load(self, load_path, load_value=True):
+        """baselines/ppo2/common_functions.py:121-142: skip variables whose name contains 'vf'
+        when ``load_value`` is False."""
+        import joblib
+        loaded = joblib.load(load_path)
+        self.arena.set_list(loaded, select=None if load_value else (lambda name: name.find('vf') == -1))
+
+    def load_value(self, load_path):
+        """baselines/ppo2/common_functions.py:145-157: only the variables whose name contains 'vf'."""
+        import joblib
+        loaded = joblib.load(load_path)
+        self.arena.set_list(loaded, select=lambda name: name.find('vf') != -1)
+
+
+class Runner(object):
+    """baselines/ppo2/common_functions.py:223-345.
+
+    The rollout loop and its bookkeeping are host code as in the reference; the collected
+    time-major arrays go to HBM once, GAE and the sf01 flatten run there.  The device
+    buffers of the last call stay available as ``self.rollout`` for ``Model.train_on_rollout``.
+    """
+
+    def __init__(self, *, env, model, nsteps, gamma, lam):
+        self.env = env
+        self.model = model
+        nenv = env.num_envs
+        self.nenv = nenv
+        self.obs = np.zeros((nenv,) + env.observation_space.shape, dtype=model.train_model.X.dtype.name)
+        self.obs[:] = env.reset()
+        self.gamma = np.array(gamma)
+        self.lam = lam
+        self.nsteps = nsteps
+        self.states = model.initial_state
+        self.dones = [False for _ in range(nenv)]
+        self.fork = getattr(model, "signature", "fork") == "fork"
+        self.rollout = None
+        self.verbose = False
+
+    def run(self, is_test=False, use_deterministic=False):
+        mb_obs, mb_rewards, mb_actions, mb_values, mb_dones, mb_neglogpacs = [], [], [], [], [], []
+        mb_states = self.states
+        epinfos = []
+        t_s = time.time()
+        ret = False
+        model, R = self.model, self.model.spec.nvalue
+        for t in range(self.nsteps):
+            if use_deterministic:
+                actions, values, self.states, neglogpacs = model.step_max(self.obs, self.states, self.dones)
+            else:
+                actions, values, self.states, neglogpacs = model.step(self.obs, self.states, self.dones)
+            mb_obs.append(self.obs.copy())
+            mb_actions.append(actions)
+            mb_values.append(values)
+            mb_neglogpacs.append(neglogpacs)
+            mb_dones.append(self.dones)
+            self.obs[:], rewards, self.dones, infos = self.env.step(actions)
+            if self.fork:
+                rewards = np.asarray(rewards)[:, :-1]                           # :262
+                # done-bootstrap off the reset observation (:265-276)
+                v_preds = None
+                for i in range(len(self.dones)):
+                    if self.dones[i]:
+                        if v_preds is None:
+                            v_preds = model.value(self.obs)
+                        if rewards[i][0] > 0:
+                            rewards[i] += self.gamma * v_preds[i]
+                        else:
+                            rewards[i][2:] += self.gamma[2:] * v_preds[i][2:]
+            if self.verbose and t % 100 == 0:
+                print(t / self.nsteps, time.time() - t_s)
+            for info in infos:
+                maybeepinfo = info.get('episode')
+                if maybeepinfo:
+                    epinfos.append(maybeepinfo)
+            mb_rewards.append(rewards)
+            if is_test:
+                if any(self.dones):
+                    ret = True
+                    break
+        T, E = len(mb_values), self.nenv
+        dev = model.device
+        spec = model.spec
+        up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+        ob_dt = np.float32 if spec.kind == _lib.POLICY_MLP else np.uint8
+        d_obs = up(np.asarray(mb_obs).reshape((T, E) + tuple(spec.ob_shape())), ob_dt)
+        d_rew = up(np.asarray(mb_rewards, dtype=np.float32).reshape(T, E, R), np.float32)
+        d_act = up(np.asarray(mb_actions), np.float32 if spec.gaussian else np.int32)
+        d_val = up(np.asarray(mb_values, dtype=np.float32).reshape(T, E, R), np.float32)
+        d_nlp = up(np.asarray(mb_neglogpacs, dtype=np.float32), np.float32)
+        d_dones = up(np.asarray(mb_dones, dtype=np.bool_).astype(np.uint8), np.uint8)
+        last_values = model.value(self.obs, self.states, self.dones)            # :304
+        d_lastv = up(np.asarray(last_values, np.float32).reshape(E, R), np.float32)
+        d_lastd = up(np.asarray(self.dones, dtype=np.bool_).astype(np.uint8), np.uint8)
+        gamma = np.broadcast_to(self.gamma.astype(np.float64), (R,)) if self.gamma.ndim else float(self.gamma)
+        advs, returns, advs_ori = hip.gae(d_rew, d_val, d_dones, d_lastv, d_lastd, gamma, self.lam)   # :308-328
+        ro = DeviceRollout(T, E, d_obs, d_act, d_rew, d_val, d_nlp, d_dones, d_lastv, d_lastd,
+                           states=(up(mb_states, np.float32) if mb_states is not None else None))
+        ro.advs_gae, ro.returns, ro.advs_ori = advs, returns, advs_ori
+        self.rollout = ro
+        squeeze = (lambda a: a) if self.fork else (lambda a: a.reshape(a.shape[0]))
+        flat = lambda d: hip.sf01(d).cpu().numpy()                              # :344, :347-352
+        out = (flat(d_obs), squeeze(flat(returns)), flat(d_dones).astype(np.bool_), flat(d_act),
+               squeeze(flat(d_val)), squeeze(flat(d_rew)), flat(d_nlp))
+        return (*out, mb_states, epinfos, ret)
+
+
+def sf01(arr):
+    """swap and then flatten axes 0 and 1 (baselines/ppo2/common_functions.py:347-352);
+    NumPy arrays go through HBM and the HIP transpose, device tensors stay on the device."""
+    if isinstance(arr, torch.Tensor):
+        return hip.sf01(arr.contiguous())
+    a = np.ascontiguousarray(arr)
+    out = hip.sf01(torch.from_numpy(a.view(np.uint8) if a.dtype == np.bool_ else a).cuda()).cpu().numpy()
+    return out.view(np.bool_) if a.dtype == np.bool_ else out
+
+
+def constfn(val):
+    def f(_):
+        return val
+    return f
+
+
+def compute_advs(max_return, values, advs_ori, action_diff, action_std):
+    """Advantage scalarisation of the fork (baselines/ppo2/common_functions.py:359-401) in
+    the HIP kernel; returns float64 [N].  The ``action_diff`` override (:396-398) is dead in
+    the reference's driver (it passes ``[]``) and is not supported."""
+    if len(action_diff) != 0:
+        raise NotImplementedError("compute_advs: action_diff override is not on the PPO2 path")
+    if isinstance(values, torch.Tensor):
+        return hip.compute_advs(max_return, values, advs_ori)
+    v = torch.from_numpy(np.ascontiguousarray(values, np.float32)).cuda()
+    a = torch.from_numpy(np.ascontiguousarray(advs_ori, np.float32)).cuda()
+    return hip.compute_advs(max_return, v, a).cpu().numpy()

@@ -1,0 +1,275 @@
+"""Policy objects with the constructor signatures and attributes of the reference's
+policies (baselines/ppo2/policies.py, baselines/a2c/policies.py).
+
+A policy here is a *description* (which network, which distribution) plus a handle on a
+flat float32 parameter arena in HBM; every forward pass runs in libppo2hip.  The ``sess``
+argument of the reference is accepted and ignored.  Variable scopes are modelled by a
+registry keyed by scope name: ``reuse=True`` shares the arena created by the
+``reuse=False`` call of the same scope, as ``tf.variable_scope(..., reuse=reuse)`` does.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib, hip
+from ..a2c.utils import ortho_init
+from ..common.distributions import make_pdtype
+
+_SCOPES = {}
+_sample_rng = np.random.RandomState(0)
+
+
+def set_sample_seed(seed):
+    """Seed of the action-sampling noise (the reference samples with TensorFlow's own RNG,
+    baselines/common/distributions.py:164-166,211-212, which no other RNG reproduces)."""
+    global _sample_rng
+    _sample_rng = np.random.RandomState(seed)
+
+
+def reset_scopes():
+    _SCOPES.clear()
+
+
+class _Placeholder:
+    """Stand-in for the tf.placeholder attributes the runner reads (``X.dtype.name``,
+    baselines/ppo2/common_functions.py:230)."""
+
+    def __init__(self, dtype, shape):
+        self.dtype = np.dtype(dtype)
+        self.shape = shape
+
+
+class ParamArena:
+    """Flat parameter vector of one variable scope (device float32) + its layout."""
+
+    def __init__(self, spec, device):
+        self.spec = spec
+        self.theta = torch.zeros(spec.nparams, dtype=torch.float32, device=device)
+        self.init_from_numpy_rng()
+
+    def init_from_numpy_rng(self, pi_scale=0.01):
+        """Initial values in variable creation order, each weight drawing its normals from the
+        global np.random stream as ortho_init does (baselines/a2c/utils.py:35): sqrt(2) trunks,
+        0.01 policy head, 1.0 value head / LSTM matrices, zero biases and logstd, unit LN gains."""
+        host = np.zeros(self.spec.nparams, np.float32)
+        for name, off, shp in self.spec.vars:
+            leaf = name.split("/")[-1]
+            n = int(np.prod(shp))
+            if leaf in ("w", "wx", "wh"):
+                if name == "pi/w":
+                    scale = pi_scale
+                elif name in ("vf/w", "v/w") or leaf in ("wx", "wh"):
+                    scale = 1.0
+                else:
+                    scale = math.sqrt(2.0)
+                host[off:off + n] = ortho_init(scale)(shp).ravel()
+            elif leaf in ("gx", "gh", "gc"):
+                host[off:off + n] = 1.0
+        self.theta.copy_(torch.from_numpy(host))
+
+    def get_list(self):
+        """Parameters as a list of NumPy arrays in creation order (what ``sess.run(params)``
+        returns for ``Model.save``, baselines/ppo2/common_functions.py:115-119)."""
+        host = self.theta.cpu().numpy()
+        return [host[off:off + int(np.prod(shp))].reshape(shp).copy() for _, off, shp in self.spec.vars]
+
+    def set_list(self, arrays, select=None):
+        host = self.theta.cpu().numpy()
+        for (name, off, shp), a in zip(self.spec.vars, arrays):
+            if select is not None and not select(name):
+                continue
+            a = np.asarray(a, np.float32)
+            n = int(np.prod(shp))
+            if a.size != n:
+                raise ValueError("checkpoint array for %s has %d entries, expected %d" % (name, a.size, n))
+            host[off:off + n] = a.ravel()
+        self.theta.copy_(torch.from_numpy(host))
+
+    def set_dict(self, d):
+        self.set_list([d[name] for name, _, _ in self.spec.vars])
+
+
+def _get_arena(scope, reuse, spec, device):
+    if reuse:
+        if scope not in _SCOPES:
+            raise ValueError("variable scope %r does not exist (reuse=True)" % scope)
+        arena = _SCOPES[scope]
+        if arena.spec.nparams != spec.nparams:
+            raise ValueError("scope %r holds a different network" % scope)
+        return arena
+    arena = ParamArena(spec, device)
+    _SCOPES[scope] = arena
+    return arena
+
+
+class _HipPolicy:
+    """Shared behaviour: forward in HIP, host-side sampling, neglogp in HIP."""
+
+    recurrent = False
+
+    def _setup(self, spec, scope, reuse, ob_space, ac_space, nbatch):
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.spec = spec
+        self.arena = _get_arena(scope, reuse, spec, self.device)
+        self.pdtype = make_pdtype(ac_space)
+        self.X = _Placeholder(ob_space.dtype if spec.kind != _lib.POLICY_MLP else np.float32,
+                              (nbatch,) + tuple(ob_space.shape))
+        self.initial_state = None
+        self._ws = None
+        self._ws_rows = 0
+
+    # -- device helpers -------------------------------------------------------------
+    def _workspace(self, B):
+        if self._ws is None or self._ws_rows < B:
+            self._ws = torch.empty(max(self.spec.forward_workspace_bytes(B), 256), dtype=torch.uint8,
+                                   device=self.device)
+            self._ws_rows = B
+        return self._ws
+
+    def _to_dev_obs(self, ob):
+        ob = np.ascontiguousarray(ob, dtype=np.float32 if self.spec.kind == _lib.POLICY_MLP else np.uint8)
+        return torch.from_numpy(ob).to(self.device)
+
+    def forward_dev(self, ob_dev, masks=None, states=None):
+        """Device obs [B, ...] -> (pi, vf, new_states) device tensors."""
+        return hip.policy_forward(self.spec, self.arena.theta, ob_dev, self._workspace(ob_dev.shape[0]), masks, states)
+
+    def _sample(self, pi_host, deterministic=False):
+        if self.spec.gaussian:
+            if deterministic:
+                return pi_host.astype(np.float32)
+            logstd = self.logstd_host()
+            return (pi_host + np.exp(logstd) * _sample_rng.standard_normal(pi_host.shape)).astype(np.float32)
+        if deterministic:
+            return np.argmax(pi_host, axis=-1).astype(np.int32)
+        u = _sample_rng.uniform(size=pi_host.shape)
+        return np.argmax(pi_host - np.log(-np.log(u)), axis=-1).astype(np.int32)   # Gumbel-max
+
+    def logstd_host(self):
+        for name, off, shp in self.spec.vars:
+            if name == "logstd":
+                return self.arena.theta[off:off + shp[-1]].cpu().numpy().reshape(1, -1)
+        raise AttributeError("policy has no logstd")
+
+    def _act(self, ob, state, mask, deterministic):
+        ob_dev = self._to_dev_obs(ob)
+        m_dev = s_dev = None
+        if self.recurrent:
+            m_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(mask).astype(np.uint8))).to(self.device)
+            s_dev = torch.from_numpy(np.ascontiguousarray(state, np.float32)).to(self.device)
+        pi, vf, snew = self.forward_dev(ob_dev, m_dev, s_dev)
+        a = self._sample(pi.cpu().numpy(), deterministic)
+        a_dev = torch.from_numpy(a).to(self.device)
+        nlp = hip.neglogp(self.spec, self.arena.theta, pi, a_dev).cpu().numpy()
+        v = vf.cpu().numpy()
+        return a, self._squeeze_v(v), (snew.cpu().numpy() if snew is not None else self.initial_state), nlp
+
+    def _squeeze_v(self, v):
+        return v
+
+    # -- the reference's callables ----------------------------------------------------
+    def step(self, ob, *args, **_kwargs):
+        state = args[0] if len(args) > 0 else None
+        mask = args[1] if len(args) > 1 else None
+        return self._act(ob, state, mask, False)
+
+    def value(self, ob, *args, **_kwargs):
+        ob_dev = self._to_dev_obs(ob)
+        m_dev = s_dev = None
+        if self.recurrent:
+            s_dev = torch.from_numpy(np.ascontiguousarray(args[0], np.float32)).to(self.device)
+            m_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(args[1]).astype(np.uint8))).to(self.device)
+        _, vf, _ = self.forward_dev(ob_dev, m_dev, s_dev)
+        return self._squeeze_v(vf.cpu().numpy())
+
+
+class MlpPolicy(_HipPolicy):
+    """Fork MlpPolicy (baselines/ppo2/policies.py:132-181): separate 256-128 tanh actor and
+    value trunks, ``REWARD_NUM`` value outputs, DiagGaussian with a state-independent logstd;
+    ``step_max`` acts with the mode.  ``vf`` results keep their [nenv, REWARD_NUM] shape."""
+
+    signature = "fork"
+    hidden = (256, 128)
+
+    def __init__(self, sess, ob_space, ac_space, REWARD_NUM, reuse=False, model_name="model"):  # pylint: disable=W0613
+        pdtype = make_pdtype(ac_space)
+        actdim = ac_space.shape[0]   # the fork reads ac_space.shape[0]: Box only (:136)
+        spec = hip.PolicySpec(_lib.POLICY_MLP, pdtype.dist, actdim, REWARD_NUM,
+                              ob_dim=int(np.prod(ob_space.shape)), hidden=self.hidden, order=_lib.ORDER_FORK)
+        self._setup(spec, model_name, reuse, ob_space, ac_space, None)
+
+    def step_max(self, ob, *_args, **_kwargs):
+        return self._act(ob, None, None, True)
+
+    @property
+    def std(self):
+        return np.exp(self.logstd_host())
+
+    def sample(self, ob):
+        """``self.sample = a1`` in the reference is the mode tensor (:181); here: mode of ``ob``."""
+        pi, _, _ = self.forward_dev(self._to_dev_obs(ob))
+        return pi.cpu().numpy()
+
+
+class MlpPolicy64(_HipPolicy):
+    """Upstream-shaped MlpPolicy (baselines/a2c/policies.py:116-146): 64-64 tanh trunks,
+    scalar value ``vf[:, 0]``, Gaussian or Categorical head from ``pdfromlatent``."""
+
+    signature = "upstream"
+    hidden = (64, 64)
+
+    def __init__(self, sess, ob_space, ac_space, nbatch, nsteps, reuse=False):  # pylint: disable=W0613
+        pdtype = make_pdtype(ac_space)
+        spec = hip.PolicySpec(_lib.POLICY_MLP, pdtype.dist, pdtype.size, 1,
+                              ob_dim=int(np.prod(ob_space.shape)), hidden=self.hidden, order=_lib.ORDER_UPSTREAM)
+        self._setup(spec, "model", reuse, ob_space, ac_space, nbatch)
+
+    def _to_dev_obs(self, ob):
+        ob = np.ascontiguousarray(ob, dtype=np.float32).reshape(len(ob), -1)   # tf.layers.flatten (:122)
+        return torch.from_numpy(ob).to(self.device)
+
+    def _squeeze_v(self, v):
+        return v[:, 0]
+
+
+class CnnPolicy(_HipPolicy):
+    """baselines/ppo2/policies.py:100-130: nature_cnn, Categorical head (init 0.01), ``vf[:, 0]``."""
+
+    signature = "upstream"
+    kind = _lib.POLICY_CNN
+    nlstm_default = 0
+
+    def __init__(self, sess, ob_space, ac_space, nbatch, nsteps, reuse=False):  # pylint: disable=W0613
+        nh, nw, nc = ob_space.shape
+        spec = hip.PolicySpec(self.kind, _lib.DIST_CATEGORICAL, ac_space.n, 1, ob_hwc=(nh, nw, nc))
+        self._setup(spec, "model", reuse, ob_space, ac_space, nbatch)
+
+    def _squeeze_v(self, v):
+        return v[:, 0]
+
+
+class LstmPolicy(_HipPolicy):
+    """baselines/ppo2/policies.py:58-98: nature_cnn -> LSTM(nlstm) with done-mask state resets."""
+
+    signature = "upstream"
+    kind = _lib.POLICY_CNN_LSTM
+    recurrent = True
+
+    def __init__(self, sess, ob_space, ac_space, nbatch, nsteps, nlstm=256, reuse=False):  # pylint: disable=W0613
+        nenv = nbatch // nsteps
+        nh, nw, nc = ob_space.shape
+        spec = hip.PolicySpec(self.kind, _lib.DIST_CATEGORICAL, ac_space.n, 1, ob_hwc=(nh, nw, nc), nlstm=nlstm)
+        self._setup(spec, "model", reuse, ob_space, ac_space, nbatch)
+        self.S = _Placeholder(np.float32, (nenv, nlstm * 2))
+        self.M = _Placeholder(np.float32, (nbatch,))
+        self.initial_state = np.zeros((nenv, nlstm * 2), dtype=np.float32)
+
+    def _squeeze_v(self, v):
+        return v[:, 0]
+
+
+class LnLstmPolicy(LstmPolicy):
+    """baselines/ppo2/policies.py:18-56: the layer-normalised LSTM variant."""
+
+    kind = _lib.POLICY_CNN_LNLSTM

@@ -1,0 +1,135 @@
+"""``learn`` of the fork's PPO2 driver (baselines/ppo2/ppo2.py:15-188) on the HIP path.
+
+Reference-literal by default: ``nminibatches`` is the minibatch SIZE (:33,:76), the
+advantage is the fork's 5-channel scalarisation (:92-95), lr/cliprange are floored (:82-83).
+``upstream=True`` switches to the upstream meaning of the same knobs (``nminibatches`` =
+count, ``advs = returns - values``), which is what policies with the upstream constructor
+signature need.
+"""
+import os
+import os.path as osp
+import time
+from collections import deque
+
+import numpy as np
+
+from .. import logger
+from .common_functions import *   # noqa: F401,F403  (Model, Runner, sf01, constfn, compute_advs, REWARD_NUM)
+from .common_functions import Model, Runner, compute_advs, constfn
+
+
+def learn(*, policy, env, nsteps, total_timesteps, ent_coef, lr,
+          vf_coef=0.5, max_grad_norm=0.5, gamma=0.99, lam=0.95,
+          log_interval=10, nminibatches=4, noptepochs=4, cliprange=0.2,
+          save_interval=0, upstream=None, comm=None, device_path=True, return_model=False):
+    if isinstance(lr, float): lr = constfn(lr)
+    else: assert callable(lr)
+    if isinstance(cliprange, float): cliprange = constfn(cliprange)
+    else: assert callable(cliprange)
+    total_timesteps = int(total_timesteps)
+    if upstream is None:
+        upstream = getattr(policy, "signature", "fork") != "fork"
+
+    nenvs = env.num_envs
+    ob_space = env.observation_space
+    ac_space = env.action_space
+    nbatch = nenvs * nsteps
+    nbatch_train = nbatch // nminibatches if upstream else nminibatches   # :31 (upstream) / :33 (fork)
+
+    make_model = lambda model_name, need_summary: Model(
+        model_name=model_name, policy=policy, ob_space=ob_space, ac_space=ac_space, nbatch_act=nenvs,
+        nbatch_train=nbatch_train, nsteps=nsteps, ent_coef=ent_coef, vf_coef=vf_coef, lr=lr(1),
+        max_grad_norm=max_grad_norm, need_summary=need_summary, upstream_loss=upstream, comm=comm)
+    model = make_model('model', need_summary=True)
+    # The fork also builds 'model_pf' and 'model_pf_2' (:45-46); they are never used by the live
+    # code and are not built here.
+
+    runner = Runner(env=env, model=model, nsteps=nsteps, gamma=gamma, lam=lam)
+    epinfobuf = deque(maxlen=100)
+    tfirststart = time.time()
+    nupdates = total_timesteps // nbatch
+    max_return = [200, 120, 0, 0, 0]   # :71
+
+    for update in range(1, nupdates + 1):
+        if upstream:
+            assert nbatch % nminibatches == 0
+        else:
+            assert nbatch % nminibatches == 0   # :74
+        tstart = time.time()
+        frac = 1.0 - (update - 1.0) / nupdates
+        lrnow = frac * lr(frac) if not upstream else lr(frac)     # fork: frac*lr(frac) (:79)
+        cliprangenow = cliprange(frac)
+        if not upstream:
+            lrnow = np.clip(lrnow, 1e-4, 1)                       # :82
+            cliprangenow = np.clip(cliprangenow, 0.1, 1)          # :83
+        obs, returns, masks, actions, values, rewards, neglogpacs, states, epinfos, ret = runner.run(is_test=False)
+        epinfobuf.extend(epinfos)
+        ro = runner.rollout
+        if upstream:
+            ro.advs = ro.advs_ori.reshape(ro.T, ro.E, -1)[:, :, 0].contiguous() if ro.advs_ori.shape[2] != 1 \
+                else ro.advs_ori.reshape(ro.T, ro.E)
+        else:
+            # advs_ori = returns - values; advs = compute_advs(max_return, values, advs_ori, [], [])  (:92-95)
+            N, R = ro.T * ro.E, ro.values.shape[2]
+            ro.advs = compute_advs(max_return[:R], ro.values.reshape(N, R), ro.advs_ori.reshape(N, R), [], []) \
+                .reshape(ro.T, ro.E)
+        if device_path:
+            lossvals = model.train_on_rollout(float(lrnow), float(cliprangenow), ro, noptepochs, nbatch_train).cpu().numpy()
+        else:
+            # the reference's host loop (:109-137): shuffle, fancy-index gather, Model.train per minibatch
+            advs_host = sf01_host(ro.advs)
+            mblossvals = []
+            if states is None:
+                inds = np.arange(nbatch)
+                for _ in range(noptepochs):
+                    np.random.shuffle(inds)
+                    for start in range(0, nbatch, nbatch_train):
+                        mbinds = inds[start:start + nbatch_train]
+                        if upstream:
+                            slices = (arr[mbinds] for arr in (obs, returns, masks, actions, values, neglogpacs))
+                        else:
+                            slices = (arr[mbinds] for arr in (obs, returns, masks, actions, values, advs_host, neglogpacs))
+                        mblossvals.append(model.train(float(lrnow), float(cliprangenow), *slices))
+            else:
+                envinds = np.arange(nenvs)
+                flatinds = np.arange(nenvs * nsteps).reshape(nenvs, nsteps)
+                envsperbatch = nbatch_train // nsteps
+                for _ in range(noptepochs):
+                    np.random.shuffle(envinds)
+                    for start in range(0, nenvs, envsperbatch):
+                        mbenvinds = envinds[start:start + envsperbatch]
+                        mbflatinds = flatinds[mbenvinds].ravel()
+                        slices = (arr[mbflatinds] for arr in (obs, returns, masks, actions, values, neglogpacs))
+                        mblossvals.append(model.train(float(lrnow), float(cliprangenow), *slices, states[mbenvinds]))
+            lossvals = np.mean(mblossvals, axis=0)
+        tnow = time.time()
+        fps = int(nbatch / (tnow - tstart))
+        if update % log_interval == 0 or update == 1:
+            logger.logkv("serial_timesteps", update * nsteps)
+            logger.logkv("nupdates", update)
+            logger.logkv("total_timesteps", update * nbatch)
+            logger.logkv("fps", fps)
+            logger.logkv('rew_mean', float(np.mean(rewards)))
+            logger.logkv('eprewmean', safemean([np.asarray(epinfo['r']).ravel()[-1] for epinfo in epinfobuf]))
+            logger.logkv('eplenmean', safemean([epinfo['l'] for epinfo in epinfobuf]))
+            logger.logkv('time_elapsed', tnow - tfirststart)
+            for (lossval, lossname) in zip(lossvals, model.loss_names):
+                logger.logkv(lossname, float(lossval))
+            logger.dumpkvs()
+        if save_interval and (update % save_interval == 0 or update == 1 or update == nupdates) and logger.get_dir():
+            checkdir = osp.join(logger.get_dir(), 'checkpoints')
+            os.makedirs(checkdir, exist_ok=True)
+            model.save(osp.join(checkdir, '%.5i' % update), osp.join(checkdir, '%.5i' % 0))
+    env.close()
+    if return_model:
+        return model
+
+
+def sf01_host(dev_tm):
+    """Device [T, E] -> host env-major flat [E*T]."""
+    from .. import hip
+    return hip.sf01(dev_tm.contiguous()).cpu().numpy()
+
+
+def safemean(xs):
+    return np.nan if len(xs) == 0 else np.mean(xs)

@@ -107,6 +107,19 @@ int ppo2hip_rng_get_state(const ppo2hip_rng *rng, uint32_t *key, int *pos);
 int ppo2hip_shuffle_i64(ppo2hip_rng *rng, int64_t *inds, int64_t n);
 int ppo2hip_shuffle_i32(ppo2hip_rng *rng, int32_t *inds, int64_t n);
 
+/* The index lists of ALL epochs of one update, produced ahead of the GPU on two worker
+ * threads: out[e] (HOST int32[n], e.g. pinned) receives `inds` after the (e+1)-th in-place
+ * shuffle of arange(n) — exactly the successive states of `inds` in the epoch loop of
+ * baselines/ppo2/ppo2.py:110-113.  One job at a time per handle; the rng must not be used
+ * by anything else between begin and wait_all (its state then equals NumPy's after the same
+ * shuffles). */
+typedef struct ppo2hip_perm ppo2hip_perm;
+ppo2hip_perm *ppo2hip_perm_create(ppo2hip_rng *rng, int64_t n, int max_epochs);
+void ppo2hip_perm_destroy(ppo2hip_perm *p);
+int ppo2hip_perm_begin(ppo2hip_perm *p, int nepochs, int32_t *const *out);
+int ppo2hip_perm_wait(ppo2hip_perm *p, int epoch);   /* blocks until out[epoch] is complete */
+int ppo2hip_perm_wait_all(ppo2hip_perm *p);
+
 /* ------------------------------------------------------------------------
  * Policy description and parameter arena
  * ---------------------------------------------------------------------- */
