@@ -29,7 +29,7 @@ static int pick_slabs(int64_t S, int64_t tiles) {
     int64_t cap = ceil_div(S, 256);
     int64_t n = want < cap ? want : cap;
     if (n < 1) n = 1;
-    if (n > 512) n = 512;
+    if (n > 128) n = 128;
     return (int)n;
 }
 
@@ -49,18 +49,27 @@ int fc_wgrad_slabs(const float *X, int ldx, const float *dY, int lddy, int64_t S
     return launch_gemm(A, B, ep, Kin + 1, N, S, n, s, "fc_wgrad");
 }
 
-__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, int nslabs, int64_t size,
-                                    float *__restrict__ dst, int accumulate) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= size) return;
+// 64 consecutive elements x 4 slab groups per workgroup: coalesced along the element axis,
+// the slab axis split over the four waves and finished through LDS in a fixed order.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int nslabs, int64_t size,
+                                                           float *__restrict__ dst, int accumulate) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int z = 0; z < nslabs; z++) s += slabs[(int64_t)z * size + i];
-    dst[i] = accumulate ? dst[i] + s : s;
+    if (i < size)
+        for (int z = grp; z < nslabs; z += 4) s += slabs[(int64_t)z * size + i];
+    part[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && i < size) {
+        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        dst[i] = accumulate ? dst[i] + t : t;
+    }
 }
 
 int reduce_slabs(const float *slabs, int nslabs, int64_t size, float *dst, bool accumulate, hipStream_t s) {
     if (size <= 0) return 0;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(size, 256)), dim3(256), 0, s, slabs, nslabs,
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(size, 64)), dim3(256), 0, s, slabs, nslabs,
                        size, dst, accumulate ? 1 : 0);
     return check_launch("reduce_slabs");
 }

@@ -163,19 +163,21 @@ __global__ __launch_bounds__(kLossBlock) void ppo_loss_kernel(LossDev a) {
         }
 }
 
-__global__ void ppo_loss_final_kernel(const double *__restrict__ partial, int nblocks, int A, int gaussian,
-                                      double inv_count, float *__restrict__ losses, float *__restrict__ dlogstd) {
-    const int j = threadIdx.x;
-    if (j < 8) {
+// one wave per output scalar: lanes stride over the per-block partials, then a wave sum
+__global__ __launch_bounds__(1024) void ppo_loss_final_kernel(const double *__restrict__ partial, int nblocks, int A,
+                                                              int gaussian, double inv_count, float *__restrict__ losses,
+                                                              float *__restrict__ dlogstd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nout = 8 + (gaussian ? A : 0);
+    for (int j = wave; j < nout; j += 16) {
         double s = 0.0;
-        if (j < 5)
-            for (int b = 0; b < nblocks; b++) s += partial[(int64_t)b * kPartialStride + j];
-        losses[j] = (float)(s * inv_count);
-    }
-    if (gaussian && dlogstd && j >= 8 && j < 8 + A) {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; b++) s += partial[(int64_t)b * kPartialStride + j];
-        dlogstd[j - 8] = (float)s;
+        if (j < 5 || j >= 8)
+            for (int b = lane; b < nblocks; b += 64) s += partial[(int64_t)b * kPartialStride + j];
+        s = wave_sum(s);
+        if (lane == 0) {
+            if (j < 8) losses[j] = (float)(s * inv_count);
+            else if (dlogstd) dlogstd[j - 8] = (float)s;
+        }
     }
 }
 
@@ -194,7 +196,7 @@ int ppo_loss_backward(const LossArgs &x, hipStream_t s) {
     hipLaunchKernelGGL(ppo_loss_kernel, dim3(nb), dim3(kLossBlock), 0, s, a);
     int rc = check_launch("ppo_loss_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(ppo_loss_final_kernel, dim3(1), dim3(128), 0, s, x.partial, nb, x.ac_dim,
+    hipLaunchKernelGGL(ppo_loss_final_kernel, dim3(1), dim3(1024), 0, s, x.partial, nb, x.ac_dim,
                        x.dist == PPO2HIP_DIST_GAUSSIAN ? 1 : 0, x.inv_count, x.losses, x.dlogstd);
     return check_launch("ppo_loss_final_kernel");
 }

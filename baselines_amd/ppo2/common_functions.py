@@ -186,7 +186,7 @@ class Model(object):
             self._copy_last = None
         return self._pp
 
-    def train_on_rollout(self, lr, cliprange, ro, noptepochs, nbatch_train):
+    def train_on_rollout(self, lr, cliprange, ro, noptepochs, nbatch_train, events=None):
         """All epochs x minibatches of one update from device-resident rollout buffers.
 
         Index generation follows baselines/ppo2/ppo2.py:110-116 (``inds`` shuffled in place
@@ -194,7 +194,8 @@ class Model(object):
         global ``np.random`` stream (or the model's own after ``seed_shuffle``).  The index
         lists are produced by the C++ pipeline while the GPU works on earlier epochs and
         reach HBM on a side stream.  Nothing here waits for the GPU: the result is a device
-        tensor holding the mean of the per-minibatch loss rows (:139).
+        tensor holding the mean of the per-minibatch loss rows (:139).  ``events``: optional list
+        that receives a (start, end) pair of timing events around every gradient evaluation.
         """
         spec = self.spec
         T, E = ro.T, ro.E
@@ -248,9 +249,16 @@ class Model(object):
             for j in range(nmb):
                 lo = j * nbatch_train
                 mb_envs = d_envs[j * envsperbatch:(j + 1) * envsperbatch] if spec.recurrent else None
+                if events is not None:
+                    ev0 = torch.cuda.Event(enable_timing=True)
+                    ev0.record(main)
                 hip.ppo_grad(spec, self.loss_desc, self.arena.theta, rref, d_idx[lo:lo + nbatch_train], nbatch_train,
                              stats[j], cliprange, 1.0 / nbatch_train, self.grads, self._losses[row], ws, mb_envs,
                              T if spec.recurrent else 0)
+                if events is not None:
+                    ev1 = torch.cuda.Event(enable_timing=True)
+                    ev1.record(main)
+                    events.append((ev0, ev1))
                 self._apply(lr)
                 row += 1
             if not spec.recurrent:

@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""PPO2 samples/sec (GAE + update) on synthetic device-resident rollouts.
+
+One "step" = one pass of the rollout-to-update path over one synthetic rollout batch:
+GAE/returns, advantage preparation, then noptepochs x (N / nbatch_train) minibatch
+updates (bit-exact index generation, gather, normalisation, forward, loss, backward,
+clip + Adam, and the gradient all-reduce when N > 1 GPUs).  Environment time is excluded
+(inputs are resident in HBM before the timed region), as the reference's `fps`
+(baselines/ppo2/ppo2.py:141) minus the rollout.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA dense peak
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: synthetic MuJoCo-shaped rollout, Gaussian MLP(64,64)
+    "mujoco_mlp64": dict(D=17, A=6, E=2048, T=256, hidden=(64, 64), R=1, upstream=True, nmb=4, noptepochs=4,
+                         lr=3e-4, cliprange=0.2, ent_coef=0.0, done_p=1.0 / 200),
+    # the same shape through the fork's own network/loss (256-128, 5 value channels)
+    "mujoco_fork": dict(D=17, A=6, E=2048, T=256, hidden=(256, 128), R=5, upstream=False, nmb=4, noptepochs=4,
+                        lr=3e-4, cliprange=0.2, ent_coef=0.0, done_p=1.0 / 200),
+}
+
+
+def dense_flops_per_sample(D, hidden, A, R):
+    """fwd 2*sum(in*out) + dW (same) + dX (same minus first layer), both trunks."""
+    h1, h2 = hidden
+    tot = 0
+    for out in (A, R):
+        fwd = 2 * (D * h1 + h1 * h2 + h2 * out)
+        dx = 2 * (h1 * h2 + h2 * out)
+        tot += fwd + fwd + dx
+    return tot
+
+
+def make_rollout(model, cfg, seed, device):
+    """Synthetic rollout in HBM: N(0,1) observations and rewards, Bernoulli dones, actions /
+    values / neglogpacs from the initial policy (so ratio ~ 1 at the first minibatch)."""
+    from baselines_amd import hip
+    from baselines_amd.ppo2.common_functions import DeviceRollout
+    T, E, D, A, R = cfg["T"], cfg["E"], cfg["D"], cfg["A"], cfg["R"]
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    obs = torch.randn((T, E, D), generator=g, device=device)
+    rewards = torch.randn((T, E, R), generator=g, device=device)
+    dones = (torch.rand((T, E), generator=g, device=device) < cfg["done_p"]).to(torch.uint8)
+    last_dones = (torch.rand((E,), generator=g, device=device) < cfg["done_p"]).to(torch.uint8)
+    spec, theta = model.spec, model.arena.theta
+    ws = torch.empty(spec.forward_workspace_bytes(T * E), dtype=torch.uint8, device=device)
+    pi, vf, _ = hip.policy_forward(spec, theta, obs.reshape(T * E, D), ws)
+    eps = torch.randn((T * E, A), generator=g, device=device)
+    actions = (pi + eps).contiguous()            # logstd = 0 at init
+    nlp = hip.neglogp(spec, theta, pi, actions)
+    last_values = torch.randn((E, R), generator=g, device=device)
+    del ws
+    return DeviceRollout(T, E, obs, actions.reshape(T, E, A), rewards, vf.reshape(T, E, R).contiguous(),
+                         nlp.reshape(T, E), dones, last_values, last_dones)
+
+
+def cpu_baseline(model, ro, cfg, budget_s=20.0):
+    """Reference-structured CPU path on the host cores (oracle = CPU restatement, "port"):
+    NumPy GAE loop over t, sf01, np.random.shuffle + fancy-index gathers, per-minibatch NumPy
+    normalisation, and the TF step restated with torch-CPU float32 eager ops."""
+    from oracle import scan, tfgraph
+    T, E, R = cfg["T"], cfg["E"], cfg["R"]
+    N = T * E
+    host = {k: getattr(ro, k).cpu().numpy() for k in ("obs", "actions", "rewards", "values", "neglogpacs", "dones",
+                                                       "last_values", "last_dones")}
+    params = {name: arr for (name, _, _), arr in zip(model.spec.vars, model.arena.get_list())}
+    oracle = tfgraph.TrainOracle(params, "mlp", "gaussian",
+                                 tfgraph.LossCfg(cfg["ent_coef"], 0.5, 0.5, cfg["upstream"]), dtype=torch.float32)
+    B = N // cfg["nmb"]
+    np.random.seed(0)
+
+    def one_update():
+        advs, rets = scan.gae(host["rewards"], host["values"], host["dones"].astype(bool), host["last_values"],
+                              host["last_dones"].astype(bool), 0.99, 0.95)
+        obs, returns, actions, values, nlps = (scan.sf01(a) for a in (host["obs"], rets, host["actions"],
+                                                                      host["values"], host["neglogpacs"]))
+        adv = (returns - values).sum(axis=1)
+        inds = np.arange(N)
+        for _ in range(cfg["noptepochs"]):
+            np.random.shuffle(inds)
+            for start in range(0, N, B):
+                mb = inds[start:start + B]
+                oracle.train(cfg["lr"], cfg["cliprange"], obs[mb], returns[mb], None, actions[mb], values[mb], adv[mb],
+                             nlps[mb])
+
+    t0 = time.perf_counter()
+    one_update()                      # warm-up, also sizes the sample
+    t_first = time.perf_counter() - t0
+    reps = int(max(1, min(5, budget_s // max(t_first, 1e-3) - 1)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one_update()
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=N / dt, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d full updates of the same workload (N=%d, %d minibatches x %d epochs), float32 torch-CPU + NumPy"
+                       % (reps, N, cfg["nmb"], cfg["noptepochs"]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="mujoco_mlp64", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    cfg = WORKLOADS[args.workload]
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+        from baselines_amd.common.mpi_adam import DataParallel
+        comm = DataParallel("mpi")
+
+    from baselines_amd import hip, spaces
+    from baselines_amd.ppo2 import policies
+    from baselines_amd.ppo2.common_functions import Model
+
+    T, E, D, A, R = cfg["T"], cfg["E"], cfg["D"], cfg["A"], cfg["R"]
+    N = T * E
+    B = N // cfg["nmb"]
+    np.random.seed(1)                     # parameter init stream (ortho_init)
+    policy = policies.MlpPolicy64 if cfg["upstream"] else policies.MlpPolicy
+    model = Model(policy=policy, ob_space=spaces.Box(-np.inf, np.inf, shape=(D,)), ac_space=spaces.Box(-1, 1, shape=(A,)),
+                  nbatch_act=E, nbatch_train=B, nsteps=T, ent_coef=cfg["ent_coef"], vf_coef=0.5, max_grad_norm=0.5,
+                  upstream_loss=cfg["upstream"], comm=comm)
+    model.seed_shuffle(0)                 # same index stream on every rank
+    ro = make_rollout(model, cfg, seed=rank, device=device)
+    gamma = 0.99 if R == 1 else [0.99] * R
+
+    def step(events=None):
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        ro.advs_gae, ro.returns, ro.advs_ori = hip.gae(ro.rewards, ro.values, ro.dones, ro.last_values, ro.last_dones,
+                                                       gamma, 0.95)
+        if events is not None:
+            e1.record()
+            events["gae"].append((e0, e1))
+        if cfg["upstream"]:
+            ro.advs = ro.advs_ori.reshape(T, E)
+        else:
+            ro.advs = hip.compute_advs([200, 120, 0, 0, 0][:R], ro.values.reshape(N, R), ro.advs_ori.reshape(N, R)).reshape(T, E)
+        return model.train_on_rollout(cfg["lr"], cfg["cliprange"], ro, cfg["noptepochs"], B,
+                                      events=None if events is None else events["grad"])
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    losses = last.cpu().numpy()
+    assert np.all(np.isfinite(losses)), "update diverged: %s" % losses
+
+    # instrumented pass: HIP events around the GAE launch and every minibatch gradient evaluation
+    events = {"gae": [], "grad": []}
+    for _ in range(3):
+        step(events)
+    torch.cuda.synchronize()
+    gae_ms = float(np.mean([a.elapsed_time(b) for a, b in events["gae"]]))
+    grad_ms = float(np.mean([a.elapsed_time(b) for a, b in events["grad"]]))
+
+    if rank == 0:
+        flops_mb = dense_flops_per_sample(D, cfg["hidden"], A, R) * B
+        achieved_tf = flops_mb / (grad_ms * 1e-3) / 1e12
+        gae_bytes = T * E * (16 * R + 1) + E * (4 * R + 1)
+        gae_gbs = gae_bytes / (gae_ms * 1e-3) / 1e9
+        out = {
+            "metric": "PPO2 samples/sec (GAE+update)", "value": world * N * args.steps / dt, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1] synthetic MuJoCo-shaped rollout: obs_dim=%d act_dim=%d Gaussian MLP%s "
+                                   "nenvs=%d nsteps=%d per GPU, %d minibatches x %d epochs, %s loss"
+                                   % (D, A, str(cfg["hidden"]).replace(" ", ""), E, T, cfg["nmb"], cfg["noptepochs"],
+                                      "upstream" if cfg["upstream"] else "fork"),
+                       "samples_per_step_per_gpu": N, "nbatch_train": B,
+                       "parallelism": "env-sharded dp%d, RCCL grad all-reduce (MpiAdam semantics)" % world if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": "ppo_grad (minibatch gather+forward+loss+backward, fp32 MFMA GEMMs)",
+                         "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "flops_per_launch": flops_mb, "ms_per_launch": grad_ms},
+            "gae_roofline": {"bound": "hbm", "kernel": "gae_kernel", "achieved": gae_gbs, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": gae_gbs / HBM_PEAK_GBS, "bytes_per_launch": gae_bytes,
+                             "ms_per_launch": gae_ms},
+            "losses": [float(x) for x in losses],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, ro, cfg)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
