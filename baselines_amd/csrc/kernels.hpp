@@ -75,6 +75,20 @@ int ppo_loss_backward(const LossArgs &a, hipStream_t s);
 int neglogp_rows(int dist, int ac_dim, const float *pi, const float *logstd, const void *actions, int64_t B,
                  float *out, hipStream_t s);
 
+int loss_final(const double *partial, int nblocks, int A_gaussian, double inv_count, float *losses, float *dlogstd,
+               hipStream_t s);
+
+// ---- fused two-trunk MLP minibatch gradient (mlp_fused.hip) -----------------------------
+struct FusedOffsets {
+    int64_t a_w1, a_w2, a_wh, v_w1, v_w2, v_wh, logstd;   // offsets of the (w, b) pairs / logstd in the arena
+};
+bool mlp_fused_supported(const ppo2hip_policy_desc &d);
+size_t mlp_fused_workspace_bytes();
+int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params,
+                   const FusedOffsets &fo, const ppo2hip_rollout &ro, const int32_t *idx, int64_t B,
+                   const double *stats, float cliprange, double inv_count, float *grads, float *losses, void *ws,
+                   size_t ws_bytes, hipStream_t s);
+
 // ---- LSTM (lstm.hip) -------------------------------------------------------------------
 // elementwise gate kernels; the matrix products go through fc_forward / fc_dgrad / fc_wgrad_slabs
 int lstm_mask_state(const float *c_in, const float *h_in, const uint8_t *masks, int64_t mask_stride,

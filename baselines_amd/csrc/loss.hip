@@ -181,6 +181,13 @@ __global__ __launch_bounds__(1024) void ppo_loss_final_kernel(const double *__re
     }
 }
 
+int loss_final(const double *partial, int nblocks, int A_gaussian, double inv_count, float *losses, float *dlogstd,
+               hipStream_t s) {
+    hipLaunchKernelGGL(ppo_loss_final_kernel, dim3(1), dim3(1024), 0, s, partial, nblocks, A_gaussian,
+                       A_gaussian > 0 ? 1 : 0, inv_count, losses, dlogstd);
+    return check_launch("ppo_loss_final_kernel");
+}
+
 int ppo_loss_backward(const LossArgs &x, hipStream_t s) {
     if (x.ac_dim < 1 || x.ac_dim > kMaxAc) {
         set_error("ppo_loss: ac_dim=%d outside [1, %d]", x.ac_dim, kMaxAc);

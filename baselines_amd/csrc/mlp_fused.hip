@@ -1,0 +1,655 @@
+// Fused minibatch gradient of the two-trunk tanh MLP policy (hidden widths 32 or 64):
+// gather -> advantage normalisation -> forward -> distribution + PPO loss -> backward ->
+// weight-gradient accumulation, in ONE launch.  What TensorFlow builds for
+// baselines/a2c/policies.py:116-146 (and the 64-wide case of baselines/ppo2/policies.py:132-181)
+// under the loss of baselines/ppo2/common_functions.py:26-63.
+//
+// Mapping to CDNA4
+//   * one wave64 owns a tile of 32 minibatch rows and one trunk (workgroups alternate between
+//     the actor and the value trunk); the grid is persistent and strides over the tiles.
+//   * every contraction is v_mfma_f32_32x32x2_f32 (exact fp32 fma chain) with the 32 samples on
+//     the lane/column axis: a layer's 32x32 accumulator (units in registers, samples on lanes)
+//     is directly the B operand of the next layer and of the input-gradient products, so the
+//     forward/backward chain never leaves registers.  The k order of such a product is the
+//     accumulator's register order: register r, lane half h <-> unit rho(r) + 4h.
+//   * weights (both orientations) sit in LDS for the whole launch and feed the A operand with
+//     conflict-free 32-float runs; the weight-gradient products contract over SAMPLES, so their
+//     operands are the activations transposed through a per-wave LDS tile (row stride 33).
+//   * weight gradients accumulate in registers across all of a wave's tiles, are summed over
+//     the workgroup's four waves in LDS and leave as one slab per workgroup; a fixed-order
+//     reduction over slabs follows (no float atomics: run-to-run reproducible).
+#include "gemm_core.hpp"
+#include "kernels.hpp"
+
+namespace ppo2hip {
+
+constexpr int kFusedThreads = 256;
+constexpr int kLdT = 33;                 // row stride of the transposed tiles (bank-conflict-free both ways)
+constexpr int kLossStride = 8 + 64;      // doubles per workgroup partial row: as ppo_loss_final_kernel expects
+
+struct TrunkOffsets {
+    int64_t w1, w2, wh;                  // offsets of (w, b) pairs in the parameter/gradient arena
+};
+
+struct FusedArgs {
+    // rollout + minibatch selection
+    const float *obs;
+    const void *actions;
+    const float *returns, *values, *neglogpacs;
+    const void *advs;
+    int adv_f64, T, E;
+    const int32_t *idx;
+    int64_t B;
+    const double *stats;
+    // network
+    const float *params;
+    TrunkOffsets actor, value;
+    int64_t logstd_off;
+    int D, A, R, dist, upstream;
+    float cliprange, ent_coef, vf_coef, inv_count;
+    // outputs
+    float *slabs;            // [2 trunks][nwg_per_trunk][slab_elems]
+    int64_t slab_elems;
+    double *loss_partial;    // [gridDim.x][kLossStride]
+};
+
+__device__ inline int rho(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// |error| <= ~1e-7 absolute over the whole range (v_exp_f32 / v_rcp_f32 are 1 ulp)
+__device__ inline float fast_tanh(float x) {
+    const float t = __expf(2.0f * x);
+    return 1.0f - 2.0f * __frcp_rn(t + 1.0f);
+}
+
+template <int H1B, int H2B>
+struct FusedLayout {
+    static constexpr int H1 = 32 * H1B, H2 = 32 * H2B;
+    // weights, per workgroup (floats)
+    static constexpr int W1 = 0;                          // [32][H1]   rows: D inputs, bias row, zeros
+    static constexpr int W2 = W1 + 32 * H1;               // [H1][H2]
+    static constexpr int W2T = W2 + H1 * H2;              // [H2][H1]
+    static constexpr int B2 = W2T + H1 * H2;              // [H2]
+    static constexpr int WH = B2 + H2;                    // [H2][32]   columns >= O zero
+    static constexpr int WHT = WH + H2 * 32;              // [32][H2]
+    static constexpr int BH = WHT + 32 * H2;              // [32]
+    static constexpr int WEIGHTS = BH + 32;
+    // per-wave scratch (floats)
+    static constexpr int XS = 0;                          // [32 samples][33]
+    static constexpr int TA = XS + 32 * kLdT;             // [H1][33]
+    static constexpr int TB = TA + H1 * kLdT;             // [H2][33]
+    static constexpr int TC = TB + H2 * kLdT;             // [32][33]
+    static constexpr int WAVE = TC + 32 * kLdT;
+    static constexpr int TOTAL = WEIGHTS + 4 * WAVE;
+    // slab image of one trunk's gradient (floats): [w1 (D+1 rows) | w2 | b2 | wh [H2][32] | bh [32]]
+    static constexpr int S_W1 = 0;
+    static constexpr int S_W2 = 32 * H1;
+    static constexpr int S_B2 = S_W2 + H1 * H2;
+    static constexpr int S_WH = S_B2 + H2;
+    static constexpr int S_BH = S_WH + H2 * 32;
+    static constexpr int SLAB = S_BH + 32;
+};
+
+template <int H1B, int H2B>
+__global__ __launch_bounds__(kFusedThreads, 1) void mlp_fused_kernel(FusedArgs g) {
+    using L = FusedLayout<H1B, H2B>;
+    constexpr int H1 = L::H1, H2 = L::H2;
+    __shared__ float lds[L::TOTAL];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const bool is_value = (blockIdx.x & 1) != 0;
+    const int nwg_trunk = gridDim.x >> 1;
+    const int wg_in_trunk = blockIdx.x >> 1;
+    const TrunkOffsets off = is_value ? g.value : g.actor;
+    const int D = g.D;
+    const int O = is_value ? g.R : g.A;
+    const bool gaussian = g.dist == PPO2HIP_DIST_GAUSSIAN;
+    const bool wide_out = (!is_value) && (!gaussian);     // categorical logits: up to 32 live rows
+    const int NRO = wide_out ? 16 : 4;                    // accumulator registers that can hold live outputs
+
+    // ---- stage this trunk's weights into LDS --------------------------------------------
+    {
+        const float *P = g.params;
+        float *w1 = lds + L::W1;
+        for (int e = tid; e < 32 * H1; e += kFusedThreads) {
+            const int k = e / H1, j = e - k * H1;
+            float v = 0.f;
+            if (k < D) v = P[off.w1 + (int64_t)k * H1 + j];
+            else if (k == D) v = P[off.w1 + (int64_t)D * H1 + j];     // bias row follows the matrix
+            w1[e] = v;
+        }
+        for (int e = tid; e < H1 * H2; e += kFusedThreads) {
+            const int k = e / H2, j = e - k * H2;
+            const float v = P[off.w2 + e];
+            lds[L::W2 + e] = v;
+            lds[L::W2T + j * H1 + k] = v;
+        }
+        for (int e = tid; e < H2; e += kFusedThreads) lds[L::B2 + e] = P[off.w2 + (int64_t)H1 * H2 + e];
+        for (int e = tid; e < H2 * 32; e += kFusedThreads) {
+            const int k = e >> 5, j = e & 31;
+            const float v = j < O ? P[off.wh + (int64_t)k * O + j] : 0.f;
+            lds[L::WH + e] = v;
+            lds[L::WHT + j * H2 + k] = v;
+        }
+        for (int e = tid; e < 32; e += kFusedThreads) lds[L::BH + e] = e < O ? P[off.wh + (int64_t)H2 * O + e] : 0.f;
+        for (int e = tid; e < 4 * L::WAVE; e += kFusedThreads) lds[L::WEIGHTS + e] = 0.f;
+    }
+    __syncthreads();
+
+    float *const xs = lds + L::WEIGHTS + wave * L::WAVE + L::XS;
+    float *const ta = lds + L::WEIGHTS + wave * L::WAVE + L::TA;
+    float *const tb = lds + L::WEIGHTS + wave * L::WAVE + L::TB;
+    float *const tc = lds + L::WEIGHTS + wave * L::WAVE + L::TC;
+    const float *const w1s = lds + L::W1;
+    const float *const w2s = lds + L::W2;
+    const float *const w2ts = lds + L::W2T;
+    const float *const b2s = lds + L::B2;
+    const float *const whs = lds + L::WH;
+    const float *const whts = lds + L::WHT;
+    const float *const bhs = lds + L::BH;
+
+    // advantage normalisation constants (baselines/ppo2/common_functions.py:67)
+    double adv_mean = 0.0, adv_rstd = 1.0;
+    if (g.stats) {
+        const double n = g.stats[2];
+        adv_mean = g.stats[0] / n;
+        double var = g.stats[1] / n - adv_mean * adv_mean;
+        var = var > 0.0 ? var : 0.0;
+        adv_rstd = 1.0 / (sqrt(var) + 1e-8);
+    }
+    float inv_std[4] = {0.f, 0.f, 0.f, 0.f};
+    float sum_logstd = 0.f;
+    if (!is_value && gaussian) {
+        for (int k = 0; k < g.A; k++) sum_logstd += g.params[g.logstd_off + k];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int k = r + 4 * lh;
+            if (k < g.A) inv_std[r] = expf(-g.params[g.logstd_off + k]);
+        }
+    }
+
+    // ---- gradient accumulators (registers, whole launch) -----------------------------------
+    f32x16 dW1[H1B], dW2[H1B][H2B], dWh[H2B];
+    float db2[H2B][16], dbh[16], dls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        dbh[r] = 0.f;
+#pragma unroll
+        for (int a = 0; a < H1B; a++) {
+            dW1[a][r] = 0.f;
+#pragma unroll
+            for (int b = 0; b < H2B; b++) dW2[a][b][r] = 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < H2B; b++) {
+            dWh[b][r] = 0.f;
+            db2[b][r] = 0.f;
+        }
+    }
+    double s_pg = 0, s_vf = 0, s_ent = 0, s_kl = 0, s_cf = 0;
+
+    const int64_t ntiles = (g.B + 31) >> 5;
+    const int64_t wave_global = (int64_t)wg_in_trunk * 4 + wave;
+    const int64_t wave_stride = (int64_t)nwg_trunk * 4;
+    const float one_lo = lh == 0 ? 1.f : 0.f;
+
+    for (int64_t tile = wave_global; tile < ntiles; tile += wave_stride) {
+        const int64_t i = tile * 32 + li;
+        const bool live = i < g.B;
+        const int64_t smp = live ? (g.idx ? (int64_t)g.idx[i] : i) : 0;
+        const int64_t row = tm_offset(smp, g.T, g.E);
+
+        // ---- gather the 32 observation rows into the x tile (+ ones feature at column D) ----
+        for (int e = lane; e < 32 * D; e += 64) {
+            const int s = e / D, c = e - s * D;
+            const int64_t srow = __shfl(row, s, 64);
+            xs[s * kLdT + c] = g.obs[srow * D + c];
+        }
+        if (lh == 0) xs[li * kLdT + D] = 1.f;
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- forward ---------------------------------------------------------------------
+        f32x16 h1[H1B], h2[H2B], out;
+#pragma unroll
+        for (int mb = 0; mb < H1B; mb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) h1[mb][r] = 0.f;
+        const int k1steps = (D + 2) >> 1;
+        for (int q = 0; q < k1steps; q++) {
+            const float b = xs[li * kLdT + 2 * q + lh];
+#pragma unroll
+            for (int mb = 0; mb < H1B; mb++)
+                h1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1s[(2 * q + lh) * H1 + 32 * mb + li], b, h1[mb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mb = 0; mb < H1B; mb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) h1[mb][r] = fast_tanh(h1[mb][r]);
+
+#pragma unroll
+        for (int m = 0; m < H2B; m++) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < H1B; mb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2s[(32 * mb + rho(r) + 4 * lh) * H2 + 32 * m + li], h1[mb][r], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b2s[32 * m + li] * one_lo, one_lo, acc, 0, 0, 0);   // + bias
+#pragma unroll
+            for (int r = 0; r < 16; r++) h2[m][r] = fast_tanh(acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) out[r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < H2B; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(whs[(32 * m + rho(r) + 4 * lh) * 32 + li], h2[m][r], out, 0, 0, 0);
+        out = __builtin_amdgcn_mfma_f32_32x32x2f32(bhs[li] * one_lo, one_lo, out, 0, 0, 0);
+
+        // transposed copies of the activations for the weight-gradient products
+#pragma unroll
+        for (int mb = 0; mb < H1B; mb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) ta[(32 * mb + rho(r) + 4 * lh) * kLdT + li] = h1[mb][r];
+#pragma unroll
+        for (int m = 0; m < H2B; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) tb[(32 * m + rho(r) + 4 * lh) * kLdT + li] = h2[m][r];
+
+        // ---- loss and d(loss)/d(out) --------------------------------------------------------
+        f32x16 dout;
+#pragma unroll
+        for (int r = 0; r < 16; r++) dout[r] = 0.f;
+        if (!is_value) {
+            float adv = 0.f, oldnlp = 0.f;
+            if (live) {
+                const double a = g.adv_f64 ? ((const double *)g.advs)[row] : (double)((const float *)g.advs)[row];
+                adv = (float)((a - adv_mean) * adv_rstd);
+                oldnlp = g.neglogpacs[row];
+            }
+            float nlp, entropy_row;
+            float zq[4] = {0.f, 0.f, 0.f, 0.f};
+            float pr[16], hterm[16];
+            int act_i = 0;
+            if (gaussian) {
+                const float *act = (const float *)g.actions + row * g.A;
+                float ss = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = r + 4 * lh;
+                    if (k < g.A) {
+                        zq[r] = (act[k] - out[r]) * inv_std[r];
+                        ss += zq[r] * zq[r];
+                    }
+                }
+                ss += __shfl_xor(ss, 32, 64);
+                nlp = 0.5f * ss + 0.91893853320467274178f * (float)g.A + sum_logstd;
+                entropy_row = sum_logstd + (0.91893853320467274178f + 0.5f) * (float)g.A;
+            } else {
+                act_i = ((const int32_t *)g.actions)[row];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (rho(r) + 4 * lh < g.A) mx = fmaxf(mx, out[r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float z0 = 0.f, la = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int k = rho(r) + 4 * lh;
+                    pr[r] = k < g.A ? expf(out[r] - mx) : 0.f;
+                    z0 += pr[r];
+                    if (k == act_i) la = out[r] - mx;
+                }
+                z0 += __shfl_xor(z0, 32, 64);
+                la += __shfl_xor(la, 32, 64);
+                const float logz = logf(z0);
+                nlp = logz - la;
+                float H = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int k = rho(r) + 4 * lh;
+                    pr[r] = pr[r] / z0;
+                    hterm[r] = k < g.A ? (out[r] - mx) - logz : 0.f;     // log p_k
+                    H -= pr[r] * hterm[r];
+                }
+                H += __shfl_xor(H, 32, 64);
+                entropy_row = H;
+            }
+            const float ratio = expf(oldnlp - nlp);
+            const float pg1 = -adv * ratio;
+            const float pg2 = -adv * fminf(fmaxf(ratio, 1.0f - g.cliprange), 1.0f + g.cliprange);
+            const float dnlp = (live && pg1 >= pg2) ? adv * ratio * g.inv_count : 0.f;
+            if (live && lh == 0) {
+                s_pg += (double)fmaxf(pg1, pg2);
+                const float d = nlp - oldnlp;
+                s_kl += 0.5 * (double)(d * d);
+                s_cf += (fabsf(ratio - 1.0f) > g.cliprange) ? 1.0 : 0.0;
+                s_ent += (double)entropy_row;
+            }
+            if (gaussian) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = r + 4 * lh;
+                    if (k < g.A) {
+                        dout[r] = dnlp * (-zq[r] * inv_std[r]);
+                        if (live) dls[r] += dnlp * (1.f - zq[r] * zq[r]) - g.ent_coef * g.inv_count;
+                    }
+                }
+            } else {
+                const float ec = live ? g.ent_coef * g.inv_count : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int k = rho(r) + 4 * lh;
+                    if (k < g.A) dout[r] = dnlp * (pr[r] - (k == act_i ? 1.f : 0.f)) + ec * pr[r] * (hterm[r] + entropy_row);
+                }
+            }
+        } else {
+            const float sc = g.inv_count / (float)g.R;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int k = r + 4 * lh;
+                if (k < g.R && live) {
+                    const float v = out[r], ret = g.returns[row * g.R + k];
+                    const float e1 = v - ret;
+                    if (g.upstream) {
+                        const float ov = g.values[row * g.R + k];
+                        const float dv = v - ov;
+                        const float vc = ov + fminf(fmaxf(dv, -g.cliprange), g.cliprange);
+                        const float e2 = vc - ret;
+                        const float l1 = e1 * e1, l2 = e2 * e2;
+                        s_vf += 0.5 * (double)fmaxf(l1, l2) / (double)g.R;
+                        const float gg = (l1 >= l2) ? e1 : ((dv >= -g.cliprange && dv <= g.cliprange) ? e2 : 0.f);
+                        dout[r] = g.vf_coef * sc * gg;
+                    } else {
+                        s_vf += (double)(e1 * e1) / (double)g.R;
+                        dout[r] = 2.f * e1 * sc;
+                    }
+                }
+            }
+        }
+        // bias gradient of the head + transposed copy of dout
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            if (r < NRO) {
+                dbh[r] += dout[r];
+                tc[(rho(r) + 4 * lh) * kLdT + li] = dout[r];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- head: weight gradient, then input gradient ----------------------------------------
+        for (int q = 0; q < 16; q++) {
+            const float b = tc[li * kLdT + 2 * q + lh];
+#pragma unroll
+            for (int m = 0; m < H2B; m++)
+                dWh[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(tb[(32 * m + li) * kLdT + 2 * q + lh], b, dWh[m], 0, 0, 0);
+        }
+        f32x16 dz2[H2B];
+#pragma unroll
+        for (int m = 0; m < H2B; m++) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            if (wide_out) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(whts[(rho(r) + 4 * lh) * H2 + 32 * m + li], dout[r], acc, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(whts[(rho(r) + 4 * lh) * H2 + 32 * m + li], dout[r], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                dz2[m][r] = acc[r] * (1.f - h2[m][r] * h2[m][r]);
+                db2[m][r] += dz2[m][r];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < H2B; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) tb[(32 * m + rho(r) + 4 * lh) * kLdT + li] = dz2[m][r];
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- layer 2: weight gradient (h1^T dz2), then input gradient -----------------------------
+        for (int q = 0; q < 16; q++) {
+            float a[H1B], b[H2B];
+#pragma unroll
+            for (int mi = 0; mi < H1B; mi++) a[mi] = ta[(32 * mi + li) * kLdT + 2 * q + lh];
+#pragma unroll
+            for (int mj = 0; mj < H2B; mj++) b[mj] = tb[(32 * mj + li) * kLdT + 2 * q + lh];
+#pragma unroll
+            for (int mi = 0; mi < H1B; mi++)
+#pragma unroll
+                for (int mj = 0; mj < H2B; mj++)
+                    dW2[mi][mj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[mj], dW2[mi][mj], 0, 0, 0);
+        }
+        f32x16 dz1[H1B];
+#pragma unroll
+        for (int mb = 0; mb < H1B; mb++) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < H2B; m++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2ts[(32 * m + rho(r) + 4 * lh) * H1 + 32 * mb + li], dz2[m][r], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) dz1[mb][r] = acc[r] * (1.f - h1[mb][r] * h1[mb][r]);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int mb = 0; mb < H1B; mb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) ta[(32 * mb + rho(r) + 4 * lh) * kLdT + li] = dz1[mb][r];
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- layer 1: weight (+ bias, through the ones feature) gradient ----------------------------
+        for (int q = 0; q < 16; q++) {
+            const float a = xs[(2 * q + lh) * kLdT + li];
+#pragma unroll
+            for (int mj = 0; mj < H1B; mj++)
+                dW1[mj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ta[(32 * mj + li) * kLdT + 2 * q + lh], dW1[mj], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- workgroup reduction of the per-wave gradient images, then one slab per workgroup --------
+    // weights and tiles are dead now: the whole LDS array holds the four per-wave images
+    __syncthreads();
+    float *img = lds + wave * L::SLAB;
+#pragma unroll
+    for (int mj = 0; mj < H1B; mj++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) img[L::S_W1 + (rho(r) + 4 * lh) * H1 + 32 * mj + li] = dW1[mj][r];
+#pragma unroll
+    for (int mi = 0; mi < H1B; mi++)
+#pragma unroll
+        for (int mj = 0; mj < H2B; mj++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) img[L::S_W2 + (32 * mi + rho(r) + 4 * lh) * H2 + 32 * mj + li] = dW2[mi][mj][r];
+#pragma unroll
+    for (int mi = 0; mi < H2B; mi++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) img[L::S_WH + (32 * mi + rho(r) + 4 * lh) * 32 + li] = dWh[mi][r];
+    // bias gradients: sum over the 32 sample lanes of each half
+#pragma unroll
+    for (int m = 0; m < H2B; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = db2[m][r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (li == 0) img[L::S_B2 + 32 * m + rho(r) + 4 * lh] = v;
+        }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float v = dbh[r];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (li == 0) img[L::S_BH + rho(r) + 4 * lh] = v;
+    }
+    __syncthreads();
+    float *slab = g.slabs + ((int64_t)(is_value ? 1 : 0) * nwg_trunk + wg_in_trunk) * g.slab_elems;
+    for (int e = tid; e < L::SLAB; e += kFusedThreads) {
+        const float *p = lds + e;
+        slab[e] = (p[0] + p[L::SLAB]) + (p[2 * L::SLAB] + p[3 * L::SLAB]);
+    }
+
+    // ---- loss partial row of this workgroup ---------------------------------------------------------
+    __shared__ double red[17];
+    double *lp = g.loss_partial + (int64_t)blockIdx.x * kLossStride;
+    double v;
+    v = block_sum(s_pg, red);  if (tid == 0) lp[0] = v;
+    v = block_sum(s_vf, red);  if (tid == 0) lp[1] = v;
+    v = block_sum(s_ent, red); if (tid == 0) lp[2] = v;
+    v = block_sum(s_kl, red);  if (tid == 0) lp[3] = v;
+    v = block_sum(s_cf, red);  if (tid == 0) lp[4] = v;
+    for (int k = 0; k < 8; k++) {
+        // dlogstd[k]: register k & 3 of lane half k >> 2
+        const double mine = (!is_value && gaussian && lh == (k >> 2)) ? (double)dls[k & 3] : 0.0;
+        v = block_sum(mine, red);
+        if (tid == 0) lp[8 + k] = v;
+    }
+}
+
+// grads[dst + e] = sum_z slabs[(base + z) * slab_elems + src + e] for a table of segments
+struct SegTable {
+    int n;
+    int64_t src[8], dst[8], size[8];
+    int trunk[8];
+};
+
+__global__ __launch_bounds__(256) void reduce_segments_kernel(const float *__restrict__ slabs, int nslabs,
+                                                              int64_t slab_elems, SegTable t, float *__restrict__ dst) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    // segments are padded to multiples of 64 elements in the block index space
+    int seg = 0;
+    int64_t base = 0;
+    for (; seg < t.n; seg++) {
+        const int64_t padded = (t.size[seg] + 63) / 64 * 64;
+        if ((int64_t)blockIdx.x * 64 < base + padded) break;
+        base += padded;
+    }
+    if (seg >= t.n) return;
+    e -= base;
+    const bool ok = e < t.size[seg];
+    float s = 0.f;
+    if (ok) {
+        const float *p = slabs + (int64_t)t.trunk[seg] * nslabs * slab_elems + t.src[seg] + e;
+        for (int z = grp; z < nslabs; z += 4) s += p[(int64_t)z * slab_elems];
+    }
+    part[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && ok) dst[t.dst[seg] + e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// head matrices: the slab image keeps 32 columns per row, the arena O columns
+__global__ __launch_bounds__(256) void reduce_heads_kernel(const float *__restrict__ slabs, int nslabs,
+                                                           int64_t slab_elems, int s_wh, int s_bh, int H2, int A,
+                                                           int64_t a_dst, int R, int64_t v_dst, float *__restrict__ dst) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int na = (H2 + 1) * A, nv = (H2 + 1) * R;
+    const int nba = (na + 63) / 64;
+    const int trunk = (int)blockIdx.x >= nba ? 1 : 0;
+    const int e = ((int)blockIdx.x - (trunk ? nba : 0)) * 64 + lane;
+    const int O = trunk ? R : A;
+    const bool ok = e < (trunk ? nv : na);
+    float s = 0.f;
+    if (ok) {
+        const int k = e / O, o = e - k * O;
+        const int src = k < H2 ? s_wh + k * 32 + o : s_bh + o;
+        const float *p = slabs + (int64_t)trunk * nslabs * slab_elems + src;
+        for (int z = grp; z < nslabs; z += 4) s += p[(int64_t)z * slab_elems];
+    }
+    part[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && ok) dst[(trunk ? v_dst : a_dst) + e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+static int fused_head_reduce(const float *slabs, int nslabs, int64_t slab_elems, int s_wh, int s_bh, int H2, int A,
+                             int64_t a_dst, int R, int64_t v_dst, float *grads, hipStream_t s) {
+    const int blocks = ((H2 + 1) * A + 63) / 64 + ((H2 + 1) * R + 63) / 64;
+    hipLaunchKernelGGL(reduce_heads_kernel, dim3(blocks), dim3(256), 0, s, slabs, nslabs, slab_elems, s_wh, s_bh, H2, A,
+                       a_dst, R, v_dst, grads);
+    return check_launch("reduce_heads_kernel");
+}
+
+bool mlp_fused_supported(const ppo2hip_policy_desc &d) {
+    if (d.kind != PPO2HIP_POLICY_MLP) return false;
+    if (d.hidden1 != 64 || d.hidden2 != 64) return false;
+    if (d.ob_dim < 1 || d.ob_dim > 31) return false;
+    if (d.nvalue > 8) return false;
+    if (d.dist == PPO2HIP_DIST_GAUSSIAN) return d.ac_dim <= 8;
+    return d.ac_dim <= 32;
+}
+
+int mlp_fused_grid() { return 512; }   // 256 workgroups per trunk: one per CU and trunk pairing
+
+size_t mlp_fused_workspace_bytes() {
+    using L = FusedLayout<2, 2>;
+    return align_up((size_t)mlp_fused_grid() * L::SLAB * sizeof(float), 256) +
+           align_up((size_t)mlp_fused_grid() * kLossStride * sizeof(double), 256);
+}
+
+int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params,
+                   const FusedOffsets &fo, const ppo2hip_rollout &ro, const int32_t *idx, int64_t B,
+                   const double *stats, float cliprange, double inv_count, float *grads, float *losses, void *ws,
+                   size_t ws_bytes, hipStream_t s) {
+    using L = FusedLayout<2, 2>;
+    static_assert(4 * L::SLAB <= L::TOTAL, "LDS must hold the four per-wave gradient images");
+    static_assert(L::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
+    if (ws_bytes < mlp_fused_workspace_bytes()) {
+        set_error("mlp_fused_grad: workspace too small");
+        return PPO2HIP_ENOSPACE;
+    }
+    const int grid = mlp_fused_grid();
+    float *slabs = (float *)ws;
+    double *lpart = (double *)((char *)ws + align_up((size_t)grid * L::SLAB * sizeof(float), 256));
+    FusedArgs g;
+    g.obs = (const float *)ro.obs; g.actions = ro.actions; g.returns = ro.returns; g.values = ro.values;
+    g.neglogpacs = ro.neglogpacs; g.advs = ro.advs; g.adv_f64 = ro.adv_f64; g.T = ro.T; g.E = ro.E;
+    g.idx = idx; g.B = B; g.stats = stats; g.params = params;
+    g.actor = TrunkOffsets{fo.a_w1, fo.a_w2, fo.a_wh};
+    g.value = TrunkOffsets{fo.v_w1, fo.v_w2, fo.v_wh};
+    g.logstd_off = fo.logstd; g.D = d.ob_dim; g.A = d.ac_dim; g.R = d.nvalue; g.dist = d.dist;
+    g.upstream = lc.upstream; g.cliprange = cliprange; g.ent_coef = lc.ent_coef;
+    g.vf_coef = lc.upstream ? lc.vf_coef : 1.0f; g.inv_count = (float)inv_count;
+    g.slabs = slabs; g.slab_elems = L::SLAB; g.loss_partial = lpart;
+    hipLaunchKernelGGL((mlp_fused_kernel<2, 2>), dim3(grid), dim3(kFusedThreads), 0, s, g);
+    int rc = check_launch("mlp_fused_kernel");
+    if (rc) return rc;
+
+    const int H1 = 64, H2 = 64, D = d.ob_dim, A = d.ac_dim, R = d.nvalue;
+    SegTable t;
+    t.n = 0;
+    auto seg = [&](int trunk, int64_t src, int64_t dst, int64_t size) {
+        t.trunk[t.n] = trunk; t.src[t.n] = src; t.dst[t.n] = dst; t.size[t.n] = size; t.n++;
+    };
+    int64_t blocks = 0;
+    for (int trunk = 0; trunk < 2; trunk++) {
+        const int64_t w1 = trunk ? fo.v_w1 : fo.a_w1, w2 = trunk ? fo.v_w2 : fo.a_w2;
+        seg(trunk, L::S_W1, w1, (int64_t)(D + 1) * H1);            // w1 rows + bias row, contiguous in the arena
+        seg(trunk, L::S_W2, w2, (int64_t)H1 * H2 + H2);            // w2 then b2 (adjacent in image and arena)
+    }
+    rc = 0;
+    for (int i = 0; i < t.n; i++) blocks += (t.size[i] + 63) / 64;
+    hipLaunchKernelGGL(reduce_segments_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, grid / 2,
+                       (int64_t)L::SLAB, t, grads);
+    if ((rc = check_launch("reduce_segments_kernel"))) return rc;
+    // heads: the image keeps 32 columns per row, the arena O columns -> dedicated small kernel
+    rc = fused_head_reduce(slabs, grid / 2, L::SLAB, L::S_WH, L::S_BH, H2, A, fo.a_wh, R, fo.v_wh, grads, s);
+    if (rc) return rc;
+    return loss_final(lpart, grid, d.dist == PPO2HIP_DIST_GAUSSIAN ? A : 0, inv_count, losses,
+                      d.dist == PPO2HIP_DIST_GAUSSIAN ? grads + fo.logstd : nullptr, s);
+}
+
+}  // namespace ppo2hip

@@ -2,6 +2,7 @@
 // gradient (gather -> forward -> loss -> backward) as a fixed sequence of kernel launches
 // on the caller's stream.  No device memory is allocated here; scratch is carved from the
 // caller's workspace.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -118,6 +119,8 @@ struct MlpBuf {
     float *X, *RET, *OLDV, *NLP, *ADV;
     void *ACT;
     float *H1a, *H2a, *PI, *H1v, *H2v, *VF, *dPI, *dVF, *dZ2, *dZ1, *slabs;
+    char *fused;
+    size_t fused_bytes;
     double *loss_partial;
     int max_slabs;
     int64_t slab_elems;
@@ -149,6 +152,8 @@ static void carve_mlp(const ppo2hip_policy_desc &d, int64_t B, Carver &c, MlpBuf
     w.slab_elems = se;
     w.slabs = c.take<float>(se);
     w.loss_partial = c.take<double>((int64_t)loss_partial_blocks(B) * 80);
+    w.fused_bytes = mlp_fused_supported(d) ? mlp_fused_workspace_bytes() : 0;
+    w.fused = c.take<char>(w.fused_bytes);
 }
 
 static int mlp_forward(const ppo2hip_policy_desc &d, const Layout &L, const float *p, const MlpBuf &w, int64_t B,
@@ -185,6 +190,13 @@ static int mlp_trunk_backward(const float *X, int D, const float *H1, int h1, co
     return 0;
 }
 
+// PPO2HIP_MLP_PATH=layered selects the layer-by-layer GEMM path for shapes the fused kernel
+// also covers (the two are checked against each other in the tests)
+static bool layered_forced() {
+    const char *e = getenv("PPO2HIP_MLP_PATH");
+    return e && std::strcmp(e, "layered") == 0;
+}
+
 static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const Layout &L, const float *p,
                     const ppo2hip_rollout &ro, const int32_t *idx, int64_t B, const double *stats, float cliprange,
                     double inv_count, float *grads, float *losses, void *ws, size_t ws_bytes, hipStream_t s) {
@@ -197,6 +209,12 @@ static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
     }
     const int D = d.ob_dim, h1 = d.hidden1, h2 = d.hidden2, A = d.ac_dim, R = d.nvalue;
     const bool gauss = d.dist == PPO2HIP_DIST_GAUSSIAN;
+    if (mlp_fused_supported(d) && !layered_forced()) {
+        FusedOffsets fo{L.off("pi_fc1/w"), L.off("pi_fc2/w"), L.off("pi/w"), L.off("vf_fc1/w"), L.off("vf_fc2/w"),
+                        L.off("vf/w"), gauss ? L.off("logstd") : 0};
+        return mlp_fused_grad(d, lc, p, fo, ro, idx, B, stats, cliprange, inv_count, grads, losses, w.fused,
+                              w.fused_bytes, s);
+    }
     GatherArgs g;
     g.ro = &ro; g.idx = idx; g.B = B; g.ob_bytes = (int64_t)D * 4; g.ac_bytes = gauss ? (int64_t)A * 4 : 4;
     g.nvalue = R; g.stats = stats; g.obs = w.X; g.actions = w.ACT; g.returns = w.RET; g.values = w.OLDV;

@@ -162,3 +162,36 @@ def test_policy_forward_and_neglogp(hip):
     nlp = hip.neglogp(spec, theta, pi, dev(act)).cpu().numpy()
     o_nlp = tfgraph.gaussian_neglogp(o_pi, p["logstd"], torch.as_tensor(act).double()).numpy()
     np.testing.assert_allclose(nlp, o_nlp, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("cfg", [CONFIGS[0], CONFIGS[2], (True, False, 9, (64, 64), 3, 5, 8, 64, 500, 0.01)])
+def test_fused_and_layered_mlp_paths_agree(hip, cfg, monkeypatch):
+    """The single-launch fused kernel and the layer-by-layer GEMM path are two routes to the
+    same gradient: they must agree to fp32 rounding (and each is checked against the oracle
+    above through whichever route the shape selects)."""
+    from baselines_amd import _lib
+    gaussian, upstream, D, hidden, A, R, T, E, B, ent_coef = cfg
+    spec, params, ro, rets, advs_tm = mlp_case(hip, gaussian, upstream, D, hidden, A, R, T, E, B, 13, ent_coef)
+    rng = np.random.RandomState(6)
+    idx = dev(rng.permutation(T * E)[:B].astype(np.int32))
+    lossd = _lib.LossDesc(ent_coef, 0.5, 0.5, 1 if upstream else 0)
+    theta = dev(util.flatten_params(params, spec))
+    ws = torch.empty(spec.grad_workspace_bytes(B), dtype=torch.uint8, device="cuda")
+    rref = hip.RolloutRef(spec, dev(ro["obs"]), dev(ro["actions"]), dev(rets), dev(ro["values"]),
+                          dev(ro["neglogpacs"]), dev(advs_tm), T, E)
+    stats = hip.adv_stats(rref.keep[5], idx, B, 1, T, E)
+    out = {}
+    for path in ("fused", "layered"):
+        monkeypatch.setenv("PPO2HIP_MLP_PATH", path)
+        grads = torch.full((spec.nparams,), float("nan"), device="cuda")
+        losses = torch.zeros(8, device="cuda")
+        hip.ppo_grad(spec, lossd, theta, rref, idx, B, stats, 0.2, 1.0 / B, grads, losses, ws)
+        torch.cuda.synchronize()
+        out[path] = (grads.cpu().numpy(), losses.cpu().numpy())
+    gf, gl = out["fused"][0], out["layered"][0]
+    assert np.all(np.isfinite(gf))
+    np.testing.assert_allclose(out["fused"][1][:5], out["layered"][1][:5], rtol=2e-5, atol=1e-7)
+    for name, off, shp in spec.vars:
+        n = int(np.prod(shp))
+        a, b = gf[off:off + n], gl[off:off + n]
+        assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-6), (name, np.abs(a - b).max(), np.abs(b).max())
