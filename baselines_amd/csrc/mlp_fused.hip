@@ -592,7 +592,7 @@ bool mlp_fused_supported(const ppo2hip_policy_desc &d) {
     return d.ac_dim <= 32;
 }
 
-int mlp_fused_grid() { return 512; }   // 256 workgroups per trunk: one per CU and trunk pairing
+int mlp_fused_grid() { return 256; }   // one resident workgroup per CU (LDS-limited), 128 per trunk
 
 size_t mlp_fused_workspace_bytes() {
     using L = FusedLayout<2, 2>;
