@@ -31,14 +31,29 @@ class DataParallel:
         ranks already scaled their sums by 1/B_global."""
         return 1.0 / self.size if self.mode == "mpi" else 1.0
 
+    def _staged(self, t):
+        """gloo carries host buffers only: device tensors are staged through the host then
+        (test rigs without RCCL, e.g. several ranks sharing one GPU)."""
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
     def allreduce_sum_(self, t):
         if self.size > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self._staged(t):
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def bcast_(self, t, root=0):
         if self.size > 1:
-            dist.broadcast(t, src=root, group=self.group)
+            if self._staged(t):
+                h = t.cpu()
+                dist.broadcast(h, src=root, group=self.group)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=root, group=self.group)
         return t
 
     def check_synced(self, theta):
@@ -46,8 +61,8 @@ class DataParallel:
         0's exactly.  Implemented as an all-reduce of (max, -min): equal iff max == min."""
         if self.size == 1:
             return True
-        hi = theta.clone()
-        lo = -theta.clone()
+        hi = theta.detach().cpu().clone() if self._staged(theta) else theta.clone()
+        lo = -hi.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
         dist.all_reduce(lo, op=dist.ReduceOp.MAX, group=self.group)
         ok = bool(torch.equal(hi, -lo))

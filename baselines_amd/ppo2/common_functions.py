@@ -204,6 +204,8 @@ class Model(object):
         rref = hip.RolloutRef(spec, ro.obs, ro.actions, ro.returns, ro.values, ro.neglogpacs, ro.advs, T, E,
                               ro.dones if spec.recurrent else None, ro.states)
         comm = self.comm if (self.comm is not None and self.comm.size > 1) else None
+        if comm is not None and comm.mode == "global":
+            return self._train_on_rollout_global(lr, cliprange, ro, rref, noptepochs, nbatch_train)
         if not spec.recurrent:
             if N % nbatch_train != 0:
                 raise AssertionError("nbatch %% nbatch_train != 0")   # baselines/ppo2/ppo2.py:74
@@ -273,6 +275,54 @@ class Model(object):
         if comm is not None:
             comm.allreduce_sum_(out)
             out = out / comm.size
+        return out.float()
+
+    def _train_on_rollout_global(self, lr, cliprange, ro, rref, noptepochs, nbatch_train):
+        """Data-parallel update that reproduces the single-process one: every rank draws the
+        same GLOBAL permutation (over all ranks' envs, ``nbatch_train`` = global minibatch size),
+        keeps the rows of the envs it owns, and the ranks all-reduce {sum a, sum a^2, n},
+        gradient sums (scaled by 1/B_global) and loss sums."""
+        spec, comm = self.spec, self.comm
+        if spec.recurrent:
+            raise NotImplementedError("global-permutation data parallelism: feed-forward policies only")
+        T, E = ro.T, ro.E
+        Ng = T * E * comm.size
+        if Ng % nbatch_train != 0:
+            raise AssertionError("nbatch %% nbatch_train != 0")
+        nmb = Ng // nbatch_train
+        total = nmb * noptepochs
+        if self._losses.shape[0] < total:
+            self._losses = torch.zeros((total, 8), dtype=torch.float32, device=self.device)
+        if not hasattr(self, "_shuffler"):
+            self._shuffler = hip.LegacyShuffler(0)
+            self._own_stream = False
+        if not self._own_stream:
+            self._shuffler.adopt_numpy()
+        inds = np.arange(Ng, dtype=np.int32)
+        stat_ws = self._stats_workspace(1)
+        row = 0
+        for _ in range(noptepochs):
+            self._shuffler.shuffle(inds)
+            for j in range(nmb):
+                local = comm.local_minibatch(inds[j * nbatch_train:(j + 1) * nbatch_train], T, E * comm.size)
+                Bl = int(local.size)
+                stats = torch.zeros((1, 3), dtype=torch.float64, device=self.device)
+                if Bl:
+                    d_idx = torch.from_numpy(local).to(self.device)
+                    hip.adv_stats(ro.advs, d_idx, Bl, 1, T, E, stat_ws, stats)
+                comm.allreduce_sum_(stats)
+                if Bl:
+                    hip.ppo_grad(spec, self.loss_desc, self.arena.theta, rref, d_idx, Bl, stats[0], cliprange,
+                                 1.0 / nbatch_train, self.grads, self._losses[row], self._workspace(Bl))
+                else:
+                    self.grads.zero_()
+                    self._losses[row].zero_()
+                self._apply(lr)
+                row += 1
+        if not self._own_stream:
+            self._shuffler.release_numpy()
+        out = self._losses[:total, :5].double().sum(dim=0) / total
+        comm.allreduce_sum_(out)       # per-rank rows are shares of the global means
         return out.float()
 
     # ------------------------------------------------------------------ misc surface

@@ -386,7 +386,7 @@ class TrainOracle:
             grads, self.last_grad_norm = clip_by_global_norm(grads, self.cfg.max_grad_norm)
         if apply:
             self.adam.update(plist, grads, lr)
-        return [float(s) for s in scalars]
+        return [float(s.detach()) for s in scalars]
 
     def numpy_params(self):
         return OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.p.items())

@@ -1,0 +1,151 @@
+"""CPU-side checks of the C-ABI library: every symbol the header declares is exported,
+the host-only entry points (permutation generator, parameter layout) agree with NumPy
+and with the oracle's variable tables, and bad arguments are refused with a message."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import tfgraph
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from baselines_amd import _lib
+    return _lib
+
+
+def test_every_declared_symbol_is_exported(lib):
+    text = open(os.path.join(ROOT, "include", "ppo2hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(ppo2hip_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 25
+    raw = ctypes.CDLL(lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), "declared in ppo2hip.h but not exported: " + name
+    assert declared == set(lib.EXPORTED), (declared ^ set(lib.EXPORTED))
+    assert lib.lib.ppo2hip_version() == 1
+
+
+@pytest.mark.parametrize("seed", [0, 1, 1234])
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_shuffle_matches_golden_and_numpy(lib, golden, seed, n):
+    from baselines_amd.hip import LegacyShuffler
+    exp = golden["perm_s%d_n%d" % (seed, n)]
+    sh = LegacyShuffler(seed)
+    for dtype in (np.int64, np.int32):
+        sh.seed(seed)
+        inds = np.arange(n, dtype=dtype)
+        for e in range(4):
+            sh.shuffle(inds)
+            np.testing.assert_array_equal(inds, exp[e])     # bit-exact, cumulative across epochs
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 255, 256, 257, 65536, 100000, 524288])
+def test_shuffle_stream_is_numpys(lib, n):
+    """Same permutation AND same generator state afterwards, so NumPy draws that follow
+    (e.g. the env's) are unchanged."""
+    from baselines_amd.hip import LegacyShuffler
+    np.random.seed(n)
+    np.random.rand(n % 7)                       # leave the stream mid-block
+    sh = LegacyShuffler()
+    sh.adopt_numpy()
+    a = np.arange(n, dtype=np.int32)
+    sh.shuffle(a)
+    sh.release_numpy()
+    after = np.random.randint(0, 2 ** 31 - 1, size=3)
+    np.random.seed(n)
+    np.random.rand(n % 7)
+    b = np.arange(n)
+    np.random.shuffle(b)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(after, np.random.randint(0, 2 ** 31 - 1, size=3))
+
+
+def test_permutation_pipeline_all_epochs(lib, golden):
+    from baselines_amd.hip import LegacyShuffler, PermPipeline
+    sh = LegacyShuffler(1234)
+    pp = PermPipeline(sh, 4096, 4, pinned=False)
+    for _ in range(2):                          # a second job restarts from arange(n), as each update does
+        sh.seed(1234)
+        pp.begin(4)
+        for e in range(4):
+            np.testing.assert_array_equal(pp.wait(e).numpy(), golden["perm_s1234_n4096"][e])
+        pp.wait_all()
+    np.random.seed(1234)
+    x = np.arange(4096)
+    for _ in range(4):
+        np.random.shuffle(x)
+    key, pos = sh.get_state()
+    st = np.random.get_state()
+    assert pos == st[2] and np.array_equal(key, st[1])
+    pp.begin(2)                                 # fewer epochs than the handle's maximum
+    pp.wait_all()
+    with pytest.raises(lib.Ppo2HipError):
+        pp.begin(5)
+
+
+def test_rng_argument_checks(lib):
+    from baselines_amd.hip import LegacyShuffler
+    sh = LegacyShuffler(0)
+    with pytest.raises(lib.Ppo2HipError) as e:
+        sh.set_state(np.zeros(624, np.uint32), 700)
+    assert "pos" in str(e.value)
+    with pytest.raises(TypeError):
+        sh.shuffle(np.arange(10, dtype=np.float32))
+
+
+def _spec(lib, **kw):
+    from baselines_amd.hip import PolicySpec
+    return PolicySpec(**kw)
+
+
+def test_param_layout_matches_reference_variable_order(lib):
+    # fork MlpPolicy: actor scope, then value scope (13 arrays, checkpoint order)
+    s = _spec(lib, kind=lib.POLICY_MLP, dist=lib.DIST_GAUSSIAN, ac_dim=6, nvalue=5, ob_dim=17, hidden=(256, 128),
+              order=lib.ORDER_FORK)
+    ref = tfgraph.mlp_param_shapes(17, (256, 128), 6, 5, True, "fork")
+    assert [v[0] for v in s.vars] == list(ref.keys()) and len(s.vars) == 13
+    assert [v[2] for v in s.vars] == [tuple(x) for x in ref.values()]
+    assert s.nparams == 76433
+    # upstream MlpPolicy(64,64)
+    s = _spec(lib, kind=lib.POLICY_MLP, dist=lib.DIST_GAUSSIAN, ac_dim=6, nvalue=1, ob_dim=17, hidden=(64, 64),
+              order=lib.ORDER_UPSTREAM)
+    ref = tfgraph.mlp_param_shapes(17, (64, 64), 6, 1, True, "upstream")
+    assert [v[0] for v in s.vars] == list(ref.keys()) and s.nparams == 11085
+    s = _spec(lib, kind=lib.POLICY_MLP, dist=lib.DIST_CATEGORICAL, ac_dim=2, nvalue=1, ob_dim=4, hidden=(64, 64),
+              order=lib.ORDER_UPSTREAM)
+    assert s.nparams == 9155 and "logstd" not in [v[0] for v in s.vars]
+    # nature_cnn family
+    for kind, lstm in ((lib.POLICY_CNN, None), (lib.POLICY_CNN_LSTM, "lstm"), (lib.POLICY_CNN_LNLSTM, "lnlstm")):
+        s = _spec(lib, kind=kind, dist=lib.DIST_CATEGORICAL, ac_dim=6, nvalue=1, ob_hwc=(84, 84, 4), nlstm=256)
+        ref = tfgraph.cnn_param_shapes(4, 6, lstm, 256)
+        assert [v[0] for v in s.vars] == list(ref.keys())
+        assert [int(np.prod(v[2])) for v in s.vars] == [int(np.prod(x)) for x in ref.values()]
+        offs = [v[1] for v in s.vars]
+        assert offs == sorted(offs) and offs[0] == 0
+
+
+def test_bad_policy_descriptions_are_refused(lib):
+    with pytest.raises(lib.Ppo2HipError):
+        _spec(lib, kind=lib.POLICY_MLP, dist=lib.DIST_GAUSSIAN, ac_dim=0, nvalue=1, ob_dim=4, hidden=(64, 64))
+    with pytest.raises(lib.Ppo2HipError):
+        _spec(lib, kind=lib.POLICY_MLP, dist=lib.DIST_GAUSSIAN, ac_dim=2, nvalue=9, ob_dim=4, hidden=(64, 64))
+    with pytest.raises(lib.Ppo2HipError):
+        _spec(lib, kind=7, dist=lib.DIST_GAUSSIAN, ac_dim=2, nvalue=1, ob_dim=4, hidden=(64, 64))
+    with pytest.raises(lib.Ppo2HipError):
+        _spec(lib, kind=lib.POLICY_CNN, dist=lib.DIST_CATEGORICAL, ac_dim=4, nvalue=1, ob_hwc=(20, 20, 4))
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is the checker: nothing under baselines_amd/ may reference it."""
+    for d, _, files in os.walk(os.path.join(ROOT, "baselines_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(d, f)
+                assert "oracle/" not in text and "oracle." not in text, os.path.join(d, f)

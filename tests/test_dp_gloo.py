@@ -1,0 +1,141 @@
+"""Data-parallel path on CPU: two gloo ranks.  The numerical work is done by the oracle
+(there is no GPU here); what is under test is the product's sharding / ownership-filter /
+all-reduce logic (baselines_amd/common/mpi_adam.py), i.e. that N ranks reproduce the
+single-process update ("global" mode) and MpiAdam's averaging ("mpi" mode)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import perm, scan, tfgraph
+from tests import util
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    D, A, T, E, B = 5, 2, 8, 12, 24
+    shapes = tfgraph.mlp_param_shapes(D, (8, 8), A, 1, True, "upstream")
+    params = util.make_params(shapes, 3, pi_scale=0.5, jitter=0.1)
+    ro = util.synthetic_mlp_rollout(np.random.RandomState(4), T, E, D, A, 1, True, params)
+    advs, rets = scan.gae(ro["rewards"], ro["values"], ro["dones"], ro["last_values"], ro["last_dones"], 0.99, 0.95)
+    flat = {k: scan.sf01(v) for k, v in dict(obs=ro["obs"], ret=rets, act=ro["actions"], val=ro["values"],
+                                             nlp=ro["neglogpacs"]).items()}
+    flat["adv"] = (flat["ret"] - flat["val"])[:, 0]
+    return params, flat, T, E, B
+
+
+def _worker(rank, world, port, mode, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from baselines_amd.common.mpi_adam import DataParallel
+    comm = DataParallel(mode)
+    params, flat, T, E, B = _problem()
+    cfg = tfgraph.LossCfg(0.01, 0.5, 0.5, True)
+    oracle = tfgraph.TrainOracle(params, "mlp", "gaussian", cfg)
+    e0, e1 = comm.env_range(E)
+    local = {k: v.reshape(E, T, *v.shape[1:])[e0:e1].reshape((e1 - e0) * T, *v.shape[1:]) for k, v in flat.items()}
+    np.random.seed(9)
+    if mode == "global":
+        epochs = perm.minibatch_indices(T * E, B, 2)          # same global permutation on every rank
+    else:
+        np.random.seed(9 + rank)
+        epochs = perm.minibatch_indices(T * (e1 - e0), B // world, 2)
+    for ep in epochs:
+        for mb in ep:
+            if mode == "global":
+                idx = comm.local_minibatch(mb, T, E)
+                a = local["adv"][idx].astype(np.float64)
+                stats = torch.tensor([a.sum(), (a * a).sum(), float(len(a))], dtype=torch.float64)
+                comm.allreduce_sum_(stats)
+                n = float(stats[2])
+                mean = float(stats[0]) / n
+                std = np.sqrt(max(float(stats[1]) / n - mean * mean, 0.0))
+                advn = ((a - mean) / (std + 1e-8)).astype(np.float32)
+                scale = len(idx) / n                          # local mean -> share of the global mean
+            else:
+                idx = mb
+                a = local["adv"][idx]
+                advn = ((a - a.mean()) / (a.std() + 1e-8)).astype(np.float32)
+                scale = 1.0
+            oracle.train(3e-4, 0.2, local["obs"][idx], local["ret"][idx], None, local["act"][idx], local["val"][idx],
+                         advn, local["nlp"][idx], normalize=False, apply=False)
+            g = torch.cat([v.reshape(-1) for v in oracle.last_grads.values()]) * scale
+            comm.allreduce_sum_(g)
+            g = g * comm.grad_scale
+            gs, off = [], 0
+            for p in oracle.p.values():
+                gs.append(g[off:off + p.numel()].reshape(p.shape))
+                off += p.numel()
+            gs, _ = tfgraph.clip_by_global_norm(gs, 0.5)
+            oracle.adam.update(list(oracle.p.values()), gs, 3e-4)
+    theta = torch.cat([p.detach().reshape(-1) for p in oracle.p.values()])
+    assert comm.check_synced(theta)
+    if rank == 0:
+        out.put(theta.numpy())
+    if mode == "mpi":
+        # a diverged replica must be detected (MpiAdam.check_synced semantics)
+        bad = theta.clone()
+        if rank == 1:
+            bad[0] += 1.0
+        with pytest.raises(AssertionError):
+            comm.check_synced(bad)
+        t = torch.full((3,), float(rank))
+        comm.bcast_(t, root=0)
+        assert float(t.sum()) == 0.0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(mode):
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_global_mode_reproduces_single_process_update():
+    theta2 = _run("global")
+    params, flat, T, E, B = _problem()
+    oracle = tfgraph.TrainOracle(params, "mlp", "gaussian", tfgraph.LossCfg(0.01, 0.5, 0.5, True))
+    np.random.seed(9)
+    for ep in perm.minibatch_indices(T * E, B, 2):
+        for mb in ep:
+            oracle.train(3e-4, 0.2, flat["obs"][mb], flat["ret"][mb], None, flat["act"][mb], flat["val"][mb],
+                         flat["adv"][mb], flat["nlp"][mb])
+    theta1 = np.concatenate([p.detach().numpy().ravel() for p in oracle.p.values()])
+    assert np.abs(theta1 - theta2).max() < 1e-6      # the float32 advantage placeholder is the only rounding difference
+
+
+def test_mpi_mode_averages_rank_gradients():
+    theta = _run("mpi")
+    assert np.all(np.isfinite(theta))
+
+
+def test_env_sharding_and_ownership_filter():
+    from baselines_amd.common.mpi_adam import DataParallel
+    comm = DataParallel("global")
+    comm.size, comm.rank = 4, 2
+    assert comm.env_range(16) == (8, 12)
+    T = 5
+    mb = np.array([0, 39, 40, 44, 59, 60, 79, 41])
+    np.testing.assert_array_equal(comm.local_minibatch(mb, T, 16), [0, 4, 19, 1])
+    with pytest.raises(ValueError):
+        comm.env_range(18)
