@@ -89,9 +89,13 @@ int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, co
                    const double *stats, float cliprange, double inv_count, float *grads, float *losses, void *ws,
                    size_t ws_bytes, hipStream_t s);
 
-// ---- LSTM (lstm.hip) -------------------------------------------------------------------
-// elementwise gate kernels; the matrix products go through fc_forward / fc_dgrad / fc_wgrad_slabs
-int lstm_mask_state(const float *c_in, const float *h_in, const uint8_t *masks, int64_t mask_stride,
-                    int nenv, int nh, float *c_out, float *h_out, hipStream_t s);
+// ---- LSTM (lstm.hip): element-wise halves of the cell; products go through the GEMM -----
+int lstm_mask(const float *c_prev, const float *h_prev, int64_t prev_stride, const uint8_t *masks, int64_t mask_stride,
+              int nenv, int nh, float *cm, float *hm, int64_t out_stride, hipStream_t s);
+int lstm_gates(float *z, int64_t z_stride, const float *cm, int64_t s_stride, int nenv, int nh, float *c, float *h,
+               float *state_out, hipStream_t s);
+int lstm_gates_bwd(float *gates, int64_t z_stride, const float *c, const float *cm, const float *dh_head,
+                   int64_t s_stride, const float *dhm_next, float *dcm_carry, const uint8_t *mask_next,
+                   int64_t mask_stride, int nenv, int nh, hipStream_t s);
 
 }  // namespace ppo2hip

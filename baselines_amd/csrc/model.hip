@@ -236,6 +236,239 @@ static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// nature_cnn (+ LSTM) policies: baselines/ppo2/policies.py:6-130, baselines/a2c/utils.py:86-108
+// ---------------------------------------------------------------------------------------
+struct CnnDims {
+    int H, W, C, h1, w1, h2, w2, h3, w3, flat, feat, nh, nact;
+    bool lstm;
+};
+static CnnDims cnn_dims(const ppo2hip_policy_desc &d) {
+    CnnDims c;
+    c.H = d.ob_h; c.W = d.ob_w; c.C = d.ob_c;
+    c.h1 = conv_out(c.H, 8, 4); c.w1 = conv_out(c.W, 8, 4);
+    c.h2 = conv_out(c.h1, 4, 2); c.w2 = conv_out(c.w1, 4, 2);
+    c.h3 = conv_out(c.h2, 3, 1); c.w3 = conv_out(c.w2, 3, 1);
+    c.flat = c.h3 * c.w3 * 64;
+    c.lstm = d.kind == PPO2HIP_POLICY_CNN_LSTM;
+    c.nh = d.nlstm;
+    c.feat = c.lstm ? d.nlstm : 512;
+    c.nact = d.ac_dim;
+    return c;
+}
+static ConvShape conv_shape(int B, int IH, int IW, int Cin, int K, int S, int Cout) {
+    return ConvShape{B, IH, IW, Cin, K, K, S, conv_out(IH, K, S), conv_out(IW, K, S), Cout};
+}
+
+struct CnnBuf {
+    uint8_t *X, *MASK;
+    int32_t *ACT;
+    float *RET, *OLDV, *NLP, *ADV;
+    float *Y1, *Y2, *Y3, *F, *PI, *VF;
+    float *Z, *HM, *CM, *C, *Hs, *S0;          // LSTM: gates [B,4nh], masked prev states, states, gathered initial state
+    float *dPI, *dVF, *dF, *dY3, *dY2, *dY1, *DH, *dhm, *dcm;
+    float *slabs;
+    int max_slabs;
+    double *loss_partial;
+};
+
+static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver &c, CnnBuf &w, bool grad) {
+    const CnnDims k = cnn_dims(d);
+    w.Y1 = c.take<float>(B * k.h1 * k.w1 * 32);
+    w.Y2 = c.take<float>(B * k.h2 * k.w2 * 64);
+    w.Y3 = c.take<float>(B * k.flat);
+    w.F = c.take<float>(B * 512);
+    if (k.lstm) {
+        w.Z = c.take<float>(B * 4 * k.nh);
+        w.HM = c.take<float>(B * k.nh); w.CM = c.take<float>(B * k.nh);
+        w.C = c.take<float>(B * k.nh); w.Hs = c.take<float>(B * k.nh);
+        w.S0 = c.take<float>((int64_t)nenv * 2 * k.nh);
+    }
+    if (!grad) return;
+    w.X = c.take<uint8_t>(B * k.H * k.W * k.C);
+    w.MASK = c.take<uint8_t>(B);
+    w.ACT = c.take<int32_t>(B);
+    w.RET = c.take<float>(B); w.OLDV = c.take<float>(B); w.NLP = c.take<float>(B); w.ADV = c.take<float>(B);
+    w.PI = c.take<float>(B * k.nact); w.VF = c.take<float>(B);
+    w.dPI = c.take<float>(B * k.nact); w.dVF = c.take<float>(B);
+    w.dF = c.take<float>(B * 512);
+    w.dY3 = c.take<float>(B * k.flat);
+    w.dY2 = c.take<float>(B * k.h2 * k.w2 * 64);
+    w.dY1 = c.take<float>(B * k.h1 * k.w1 * 32);
+    if (k.lstm) {
+        w.DH = c.take<float>(B * k.nh);
+        w.dhm = c.take<float>((int64_t)nenv * k.nh); w.dcm = c.take<float>((int64_t)nenv * k.nh);
+    }
+    // weight-gradient slabs: the largest layer decides
+    int64_t se = 0;
+    int ms = 1;
+    auto consider = [&](int64_t S, int Kin, int N) {
+        const int s = wgrad_max_slabs(S, Kin, N);
+        const int64_t e = (int64_t)s * (Kin + 1) * N;
+        if (e > se) se = e;
+        if (s > ms) ms = s;
+    };
+    consider(B * k.h1 * k.w1, 8 * 8 * k.C, 32);
+    consider(B * k.h2 * k.w2, 4 * 4 * 32, 64);
+    consider(B * k.h3 * k.w3, 3 * 3 * 64, 64);
+    consider(B, k.flat, 512);
+    consider(B, k.feat, k.nact);
+    consider(B, k.feat, 1);
+    if (k.lstm) { consider(B, 512, 4 * k.nh); consider(B, k.nh, 4 * k.nh); }
+    w.max_slabs = ms;
+    w.slabs = c.take<float>(se);
+    w.loss_partial = c.take<double>((int64_t)loss_partial_blocks(B) * 80);
+}
+
+// conv trunk + fc1: X (uint8 NHWC) -> F [B, 512]
+static int cnn_trunk_forward(const ppo2hip_policy_desc &d, const Layout &L, const float *p, const void *X,
+                             const CnnBuf &w, int64_t B, hipStream_t s) {
+    const CnnDims k = cnn_dims(d);
+    int rc;
+    if ((rc = conv_forward(X, true, p + L.off("c1/w"), p + L.off("c1/b"), w.Y1, conv_shape((int)B, k.H, k.W, k.C, 8, 4, 32), s))) return rc;
+    if ((rc = conv_forward(w.Y1, false, p + L.off("c2/w"), p + L.off("c2/b"), w.Y2, conv_shape((int)B, k.h1, k.w1, 32, 4, 2, 64), s))) return rc;
+    if ((rc = conv_forward(w.Y2, false, p + L.off("c3/w"), p + L.off("c3/b"), w.Y3, conv_shape((int)B, k.h2, k.w2, 64, 3, 1, 64), s))) return rc;
+    return fc_forward(w.Y3, k.flat, p + L.off("fc1/w"), p + L.off("fc1/b"), w.F, 512, (int)B, 512, k.flat, ACT_RELU, false, s);
+}
+
+// LSTM over rows e*T + t (T steps, nenv envs): F [B,512] -> Hs [B,nh]; masks [B]; S0 [nenv, 2nh]
+static int lstm_forward_all(const ppo2hip_policy_desc &d, const Layout &L, const float *p, const CnnBuf &w,
+                            const uint8_t *masks, int nenv, int T, float *state_out, hipStream_t s) {
+    const int nh = d.nlstm;
+    const int64_t B = (int64_t)nenv * T;
+    int rc;
+    // x wx + b for every row at once
+    if ((rc = fc_forward(w.F, 512, p + L.off("lstm1/wx"), p + L.off("lstm1/b"), w.Z, 4 * nh, (int)B, 4 * nh, 512, ACT_NONE, false, s))) return rc;
+    const float *wh = p + L.off("lstm1/wh");
+    for (int t = 0; t < T; t++) {
+        const float *cprev = t == 0 ? w.S0 : w.C + (int64_t)(t - 1) * nh;
+        const float *hprev = t == 0 ? w.S0 + nh : w.Hs + (int64_t)(t - 1) * nh;
+        const int64_t pstride = t == 0 ? 2 * nh : (int64_t)T * nh;
+        if ((rc = lstm_mask(cprev, hprev, pstride, masks + t, T, nenv, nh, w.CM + (int64_t)t * nh, w.HM + (int64_t)t * nh, (int64_t)T * nh, s))) return rc;
+        // z_t += hm_t wh   (rows of step t are T rows apart)
+        if ((rc = fc_forward(w.HM + (int64_t)t * nh, T * nh, wh, nullptr, w.Z + (int64_t)t * 4 * nh, T * 4 * nh, nenv, 4 * nh, nh, ACT_NONE, true, s))) return rc;
+        if ((rc = lstm_gates(w.Z + (int64_t)t * 4 * nh, (int64_t)T * 4 * nh, w.CM + (int64_t)t * nh, (int64_t)T * nh, nenv, nh,
+                             w.C + (int64_t)t * nh, w.Hs + (int64_t)t * nh, t == T - 1 ? state_out : nullptr, s))) return rc;
+    }
+    return 0;
+}
+
+static int wgrad_into(const float *X, int ldx, const float *dY, int lddy, int64_t S, int Kin, int N, float *slabs,
+                      int max_slabs, float *dst, hipStream_t s) {
+    int ns = 0;
+    int rc = fc_wgrad_slabs(X, ldx, dY, lddy, S, Kin, N, slabs, max_slabs, &ns, s);
+    if (rc) return rc;
+    return reduce_slabs(slabs, ns, (int64_t)(Kin + 1) * N, dst, false, s);
+}
+
+static int conv_wgrad_into(const void *X, bool u8, const float *dY, const ConvShape &c, float *slabs, int max_slabs,
+                           float *dst, hipStream_t s) {
+    int ns = 0;
+    int rc = conv_wgrad_slabs(X, u8, dY, c, slabs, max_slabs, &ns, s);
+    if (rc) return rc;
+    return reduce_slabs(slabs, ns, (int64_t)(c.KH * c.KW * c.Cin + 1) * c.Cout, dst, false, s);
+}
+
+static int cnn_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const Layout &L, const float *p,
+                    const ppo2hip_rollout &ro, const int32_t *idx, int64_t B, const int32_t *mb_envs, int nsteps_mb,
+                    const double *stats, float cliprange, double inv_count, float *grads, float *losses, void *ws,
+                    size_t ws_bytes, hipStream_t s) {
+    const CnnDims k = cnn_dims(d);
+    if (d.dist != PPO2HIP_DIST_CATEGORICAL) { set_error("ppo_grad: nature_cnn policies are Categorical"); return PPO2HIP_EUNSUPPORTED; }
+    int nenv = 1, T = 1;
+    if (k.lstm) {
+        if (nsteps_mb < 1 || B % nsteps_mb != 0 || !mb_envs || !ro.masks || !ro.states) {
+            set_error("ppo_grad: recurrent policy needs masks, states, mb_envs and nsteps_mb dividing B");
+            return PPO2HIP_EINVAL;
+        }
+        T = nsteps_mb;
+        nenv = (int)(B / T);
+    }
+    Carver c(ws, ws_bytes);
+    CnnBuf w{};
+    carve_cnn(d, B, nenv, c, w, true);
+    if (!c.ok) { set_error("ppo_grad: workspace too small (%zu < %zu bytes)", ws_bytes, c.used()); return PPO2HIP_ENOSPACE; }
+    GatherArgs g;
+    g.ro = &ro; g.idx = idx; g.B = B; g.ob_bytes = (int64_t)k.H * k.W * k.C; g.ac_bytes = 4; g.nvalue = 1; g.stats = stats;
+    g.obs = w.X; g.actions = w.ACT; g.returns = w.RET; g.values = w.OLDV; g.neglogpacs = w.NLP; g.advs = w.ADV;
+    g.masks = k.lstm ? w.MASK : nullptr;
+    int rc;
+    if ((rc = gather_minibatch(g, s))) return rc;
+    if ((rc = cnn_trunk_forward(d, L, p, w.X, w, B, s))) return rc;
+    const float *feat = w.F;
+    if (k.lstm) {
+        if ((rc = gather_states(ro.states, mb_envs, nenv, 2 * k.nh, w.S0, s))) return rc;
+        if ((rc = lstm_forward_all(d, L, p, w, w.MASK, nenv, T, nullptr, s))) return rc;
+        feat = w.Hs;
+    }
+    if ((rc = fc_forward(feat, k.feat, p + L.off("pi/w"), p + L.off("pi/b"), w.PI, k.nact, (int)B, k.nact, k.feat, ACT_NONE, false, s))) return rc;
+    if ((rc = fc_forward(feat, k.feat, p + L.off("v/w"), p + L.off("v/b"), w.VF, 1, (int)B, 1, k.feat, ACT_NONE, false, s))) return rc;
+    LossArgs la;
+    la.dist = d.dist; la.ac_dim = k.nact; la.nvalue = 1; la.B = B; la.pi = w.PI; la.logstd = nullptr; la.vf = w.VF;
+    la.actions = w.ACT; la.advs = w.ADV; la.returns = w.RET; la.oldv = w.OLDV; la.oldnlp = w.NLP; la.cliprange = cliprange;
+    la.cfg = lc; la.inv_count = inv_count; la.dpi = w.dPI; la.dvf = w.dVF; la.partial = w.loss_partial; la.losses = losses;
+    la.dlogstd = nullptr;
+    if ((rc = ppo_loss_backward(la, s))) return rc;
+    // heads
+    if ((rc = wgrad_into(feat, k.feat, w.dPI, k.nact, B, k.feat, k.nact, w.slabs, w.max_slabs, grads + L.off("pi/w"), s))) return rc;
+    if ((rc = wgrad_into(feat, k.feat, w.dVF, 1, B, k.feat, 1, w.slabs, w.max_slabs, grads + L.off("v/w"), s))) return rc;
+    if (!k.lstm) {
+        // dF = (dPI Wpi^T + dVF Wv^T) * relu'(F)
+        if ((rc = fc_dgrad(w.dPI, k.nact, p + L.off("pi/w"), 512, k.nact, w.F, 512, ACT_RELU, w.dF, 512, (int)B, false, s))) return rc;
+        if ((rc = fc_dgrad(w.dVF, 1, p + L.off("v/w"), 512, 1, w.F, 512, ACT_RELU, w.dF, 512, (int)B, true, s))) return rc;
+    } else {
+        const int nh = k.nh;
+        if ((rc = fc_dgrad(w.dPI, k.nact, p + L.off("pi/w"), nh, k.nact, nullptr, 0, ACT_NONE, w.DH, nh, (int)B, false, s))) return rc;
+        if ((rc = fc_dgrad(w.dVF, 1, p + L.off("v/w"), nh, 1, nullptr, 0, ACT_NONE, w.DH, nh, (int)B, true, s))) return rc;
+        const float *wh = p + L.off("lstm1/wh");
+        for (int t = T - 1; t >= 0; t--) {
+            const uint8_t *mnext = t == T - 1 ? nullptr : w.MASK + (t + 1);
+            if ((rc = lstm_gates_bwd(w.Z + (int64_t)t * 4 * nh, (int64_t)T * 4 * nh, w.C + (int64_t)t * nh, w.CM + (int64_t)t * nh,
+                                     w.DH + (int64_t)t * nh, (int64_t)T * nh, w.dhm, w.dcm, mnext, T, nenv, nh, s))) return rc;
+            // dhm = dz_t wh^T
+            if (t > 0 && (rc = fc_dgrad(w.Z + (int64_t)t * 4 * nh, T * 4 * nh, wh, nh, 4 * nh, nullptr, 0, ACT_NONE, w.dhm, nh, nenv, false, s))) return rc;
+        }
+        // Z now holds dz for every row.  wx first: its appended ones-row lands on the start of the (wh, b)
+        // block that the next product overwrites.
+        if ((rc = wgrad_into(w.F, 512, w.Z, 4 * nh, B, 512, 4 * nh, w.slabs, w.max_slabs, grads + L.off("lstm1/wx"), s))) return rc;
+        if ((rc = wgrad_into(w.HM, nh, w.Z, 4 * nh, B, nh, 4 * nh, w.slabs, w.max_slabs, grads + L.off("lstm1/wh"), s))) return rc;
+        if ((rc = fc_dgrad(w.Z, 4 * nh, p + L.off("lstm1/wx"), 512, 4 * nh, w.F, 512, ACT_RELU, w.dF, 512, (int)B, false, s))) return rc;
+    }
+    // fc1
+    if ((rc = wgrad_into(w.Y3, k.flat, w.dF, 512, B, k.flat, 512, w.slabs, w.max_slabs, grads + L.off("fc1/w"), s))) return rc;
+    if ((rc = fc_dgrad(w.dF, 512, p + L.off("fc1/w"), k.flat, 512, w.Y3, k.flat, ACT_RELU, w.dY3, k.flat, (int)B, false, s))) return rc;
+    // conv3, conv2, conv1
+    const ConvShape c3 = conv_shape((int)B, k.h2, k.w2, 64, 3, 1, 64), c2 = conv_shape((int)B, k.h1, k.w1, 32, 4, 2, 64),
+                    c1 = conv_shape((int)B, k.H, k.W, k.C, 8, 4, 32);
+    if ((rc = conv_wgrad_into(w.Y2, false, w.dY3, c3, w.slabs, w.max_slabs, grads + L.off("c3/w"), s))) return rc;
+    if ((rc = conv_dgrad(w.dY3, p + L.off("c3/w"), w.Y2, w.dY2, c3, s))) return rc;
+    if ((rc = conv_wgrad_into(w.Y1, false, w.dY2, c2, w.slabs, w.max_slabs, grads + L.off("c2/w"), s))) return rc;
+    if ((rc = conv_dgrad(w.dY2, p + L.off("c2/w"), w.Y1, w.dY1, c2, s))) return rc;
+    if ((rc = conv_wgrad_into(w.X, true, w.dY1, c1, w.slabs, w.max_slabs, grads + L.off("c1/w"), s))) return rc;
+    return 0;
+}
+
+static int cnn_policy_forward(const ppo2hip_policy_desc &d, const Layout &L, const float *p, const void *obs, int64_t B,
+                              const uint8_t *masks, const float *states_in, float *pi, float *vf, float *states_out,
+                              void *ws, size_t ws_bytes, hipStream_t s) {
+    const CnnDims k = cnn_dims(d);
+    Carver c(ws, ws_bytes);
+    CnnBuf w{};
+    carve_cnn(d, B, (int)B, c, w, false);
+    if (!c.ok || !ws) { set_error("policy_forward: workspace too small (%zu < %zu)", ws_bytes, c.used()); return PPO2HIP_ENOSPACE; }
+    int rc;
+    if ((rc = cnn_trunk_forward(d, L, p, obs, w, B, s))) return rc;
+    const float *feat = w.F;
+    if (k.lstm) {
+        if (!masks || !states_in || !states_out) { set_error("policy_forward: recurrent policy needs masks and states"); return PPO2HIP_EINVAL; }
+        PPO2HIP_CHECK_HIP(hipMemcpyAsync(w.S0, states_in, (size_t)B * 2 * k.nh * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if ((rc = lstm_forward_all(d, L, p, w, masks, (int)B, 1, states_out, s))) return rc;
+        feat = w.Hs;
+    }
+    if ((rc = fc_forward(feat, k.feat, p + L.off("pi/w"), p + L.off("pi/b"), pi, k.nact, (int)B, k.nact, k.feat, ACT_NONE, false, s))) return rc;
+    return fc_forward(feat, k.feat, p + L.off("v/w"), p + L.off("v/b"), vf, 1, (int)B, 1, k.feat, ACT_NONE, false, s);
+}
+
 }  // namespace ppo2hip
 
 using namespace ppo2hip;
@@ -265,12 +498,19 @@ extern "C" int ppo2hip_param_layout(const ppo2hip_policy_desc *desc, int max_var
     return n;
 }
 
+static bool cnn_kind(const ppo2hip_policy_desc &d) { return d.kind == PPO2HIP_POLICY_CNN || d.kind == PPO2HIP_POLICY_CNN_LSTM; }
+
 extern "C" size_t ppo2hip_forward_workspace_bytes(const ppo2hip_policy_desc *desc, int64_t B) {
     if (!desc || B < 0) return 0;
+    Carver c(nullptr, 0);
     if (desc->kind == PPO2HIP_POLICY_MLP) {
-        Carver c(nullptr, 0);
         MlpBuf w;
         carve_mlp(*desc, B, c, w, false);
+        return c.used();
+    }
+    if (cnn_kind(*desc)) {
+        CnnBuf w{};
+        carve_cnn(*desc, B, (int)B, c, w, false);
         return c.used();
     }
     return 0;
@@ -278,10 +518,15 @@ extern "C" size_t ppo2hip_forward_workspace_bytes(const ppo2hip_policy_desc *des
 
 extern "C" size_t ppo2hip_grad_workspace_bytes(const ppo2hip_policy_desc *desc, int64_t B) {
     if (!desc || B < 0) return 0;
+    Carver c(nullptr, 0);
     if (desc->kind == PPO2HIP_POLICY_MLP) {
-        Carver c(nullptr, 0);
         MlpBuf w;
         carve_mlp(*desc, B, c, w, true);
+        return c.used();
+    }
+    if (cnn_kind(*desc)) {
+        CnnBuf w{};
+        carve_cnn(*desc, B, (int)B, c, w, true);   // nenv <= B bounds the per-env carry buffers
         return c.used();
     }
     return 0;
@@ -305,8 +550,10 @@ extern "C" int ppo2hip_policy_forward(const ppo2hip_policy_desc *desc, const flo
         w.X = (float *)obs;   // observations are already a dense [B, ob_dim] block
         return mlp_forward(*desc, L, params, w, B, pi, vf, s);
     }
-    (void)masks; (void)states_in; (void)states_out;
-    set_error("policy_forward: policy kind %d not built yet", desc->kind);
+    if (cnn_kind(*desc))
+        return cnn_policy_forward(*desc, L, params, obs, B, masks, states_in, pi, vf, states_out, workspace,
+                                  workspace_bytes, s);
+    set_error("policy_forward: policy kind %d (layer-normalised LSTM) is not built", desc->kind);
     return PPO2HIP_EUNSUPPORTED;
 }
 
@@ -337,7 +584,9 @@ extern "C" int ppo2hip_ppo_grad(const ppo2hip_policy_desc *desc, const ppo2hip_l
     if (desc->kind == PPO2HIP_POLICY_MLP)
         return mlp_grad(*desc, *loss, L, params, *rollout, idx, B, stats, cliprange, inv_count, grads, losses,
                         workspace, workspace_bytes, s);
-    (void)mb_envs; (void)nsteps_mb;
-    set_error("ppo_grad: policy kind %d not built yet", desc->kind);
+    if (cnn_kind(*desc))
+        return cnn_grad(*desc, *loss, L, params, *rollout, idx, B, mb_envs, nsteps_mb, stats, cliprange, inv_count, grads,
+                        losses, workspace, workspace_bytes, s);
+    set_error("ppo_grad: policy kind %d (layer-normalised LSTM) is not built", desc->kind);
     return PPO2HIP_EUNSUPPORTED;
 }

@@ -47,13 +47,13 @@ def mlp_param_shapes(ob_dim, hidden, ac_dim, nvalue, gaussian, order="fork"):
     return OrderedDict(actor + value + head)
 
 
-def cnn_param_shapes(nc, nact, lstm=None, nlstm=256):
+def cnn_param_shapes(nc, nact, lstm=None, nlstm=256, flat=3136):
     """``nature_cnn`` + heads, ``baselines/ppo2/policies.py:6-16,58-130``;
     ``lstm`` in (None, "lstm", "lnlstm") inserts ``baselines/a2c/utils.py:86-147``."""
     shapes = [("c1/w", (8, 8, nc, 32)), ("c1/b", (32,)),
               ("c2/w", (4, 4, 32, 64)), ("c2/b", (64,)),
               ("c3/w", (3, 3, 64, 64)), ("c3/b", (64,)),
-              ("fc1/w", (3136, 512)), ("fc1/b", (512,))]
+              ("fc1/w", (flat, 512)), ("fc1/b", (512,))]
     feat = 512
     if lstm == "lstm":
         shapes += [("lstm1/wx", (512, 4 * nlstm)), ("lstm1/wh", (nlstm, 4 * nlstm)),

@@ -1,0 +1,127 @@
+"""nature_cnn and cnn+LSTM policies: minibatch gradient, losses and the optimiser step of the
+HIP path (implicit-GEMM convolutions, LSTM with done-mask resets, env-sequence minibatches)
+against the float64 restatement.  GPU only.  Tolerances: losses rtol 5e-5; gradients 5e-5 of
+the per-variable max (contractions up to K = 3136 in fp32); post-update parameters atol 2e-6."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scan, tfgraph
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available()
+    from baselines_amd import hip as h
+    return h
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def _check(hip, spec, params, oracle, o_losses, theta, grads, losses, upstream=True, lr=2.5e-4):
+    torch.cuda.synchronize()
+    g = grads.cpu().numpy()
+    assert np.all(np.isfinite(g))
+    np.testing.assert_allclose(losses.cpu().numpy()[:5], o_losses, rtol=5e-5, atol=1e-7)
+    for name, off, shp in spec.vars:
+        ref = oracle.last_grads[name].numpy().ravel()
+        got = g[off:off + ref.size]
+        tol = 5e-5 * max(np.abs(ref).max(), 1e-6)
+        assert np.abs(got - ref).max() <= tol, (name, float(np.abs(got - ref).max()), tol)
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    scratch = hip.adam_scratch(spec.nparams, "cuda")
+    hip.adam_step(theta, grads, m, v, lr, 1, scratch, max_grad_norm=0.5)
+    new = util.unflatten(theta.cpu().numpy(), spec, params)
+    o_params = oracle.numpy_params()
+    assert max(float(np.abs(new[k] - o_params[k]).max()) for k in new) <= 2e-6
+
+
+@pytest.mark.parametrize("hwc,nact,T,E,B", [((36, 36, 2), 4, 4, 6, 20), ((44, 52, 4), 6, 3, 8, 24), ((84, 84, 4), 6, 2, 8, 16)])
+def test_cnn_policy_grad(hip, hwc, nact, T, E, B):
+    from baselines_amd import _lib
+    spec = hip.PolicySpec(_lib.POLICY_CNN, _lib.DIST_CATEGORICAL, nact, 1, ob_hwc=hwc)
+    shapes = tfgraph.cnn_param_shapes(hwc[2], nact, None, flat=util.cnn_flat(hwc[0], hwc[1]))
+    params = util.make_params(shapes, 5, pi_scale=0.5, jitter=0.002)
+    rng = np.random.RandomState(6)
+    ro = util.synthetic_cnn_rollout(rng, T, E, hwc, nact, params)
+    _, rets = scan.gae(ro["rewards"], ro["values"], ro["dones"], ro["last_values"], ro["last_dones"], 0.99, 0.95)
+    advs_tm = (rets - ro["values"])[:, :, 0]
+    idx = rng.permutation(T * E)[:B].astype(np.int32)
+    f = lambda a: scan.sf01(a)[idx]
+    oracle = tfgraph.TrainOracle(params, "cnn", "categorical", tfgraph.LossCfg(0.01, 0.5, 0.5, True))
+    o_losses = oracle.train(2.5e-4, 0.1, f(ro["obs"]), f(rets), None, f(ro["actions"]), f(ro["values"]), f(advs_tm),
+                            f(ro["neglogpacs"]))
+    theta = dev(util.flatten_params(params, spec))
+    grads = torch.full((spec.nparams,), float("nan"), device="cuda")
+    losses = torch.zeros(8, device="cuda")
+    ws = torch.empty(spec.grad_workspace_bytes(B), dtype=torch.uint8, device="cuda")
+    rref = hip.RolloutRef(spec, dev(ro["obs"]), dev(ro["actions"]), dev(rets), dev(ro["values"]), dev(ro["neglogpacs"]),
+                          dev(advs_tm), T, E)
+    d_idx = dev(idx)
+    stats = hip.adv_stats(rref.keep[5], d_idx, B, 1, T, E)
+    hip.ppo_grad(spec, _lib.LossDesc(0.01, 0.5, 0.5, 1), theta, rref, d_idx, B, stats, 0.1, 1.0 / B, grads, losses, ws)
+    _check(hip, spec, params, oracle, o_losses, theta, grads, losses)
+    # forward entry point used by the runner
+    fws = torch.empty(spec.forward_workspace_bytes(E), dtype=torch.uint8, device="cuda")
+    pi, vf, _ = hip.policy_forward(spec, dev(util.flatten_params(params, spec)), dev(ro["obs"][0]), fws)
+    p = tfgraph.to_torch(params, torch.float64, requires_grad=False)
+    o_pi, o_vf = tfgraph.cnn_forward(p, torch.as_tensor(ro["obs"][0]))
+    np.testing.assert_allclose(pi.cpu().numpy(), o_pi.numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(vf.cpu().numpy(), o_vf.numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("hwc,nact,T,E,nenv_mb,nlstm", [((36, 36, 2), 4, 6, 6, 3, 32), ((44, 52, 4), 5, 5, 8, 4, 64),
+                                                        ((84, 84, 4), 6, 4, 4, 2, 256)])
+def test_cnn_lstm_policy_grad(hip, hwc, nact, T, E, nenv_mb, nlstm):
+    """Env-sequence minibatch (baselines/ppo2/ppo2.py:124-136): whole env rows, masks reset the state."""
+    from baselines_amd import _lib
+    spec = hip.PolicySpec(_lib.POLICY_CNN_LSTM, _lib.DIST_CATEGORICAL, nact, 1, ob_hwc=hwc, nlstm=nlstm)
+    shapes = tfgraph.cnn_param_shapes(hwc[2], nact, "lstm", nlstm, flat=util.cnn_flat(hwc[0], hwc[1]))
+    params = util.make_params(shapes, 7, pi_scale=0.5, jitter=0.002)
+    rng = np.random.RandomState(8)
+    ro = util.synthetic_cnn_rollout(rng, T, E, hwc, nact, params, kind="lstm", nlstm=nlstm)
+    ro["states"] = (0.3 * rng.randn(E, 2 * nlstm)).astype(np.float32)     # non-trivial initial states
+    _, rets = scan.gae(ro["rewards"], ro["values"], ro["dones"], ro["last_values"], ro["last_dones"], 0.99, 0.95)
+    advs_tm = (rets - ro["values"])[:, :, 0]
+    envs = rng.permutation(E)[:nenv_mb].astype(np.int32)
+    flat = (envs[:, None] * T + np.arange(T)[None, :]).ravel().astype(np.int32)
+    B = flat.size
+    f = lambda a: scan.sf01(a)[flat]
+    oracle = tfgraph.TrainOracle(params, "lstm", "categorical", tfgraph.LossCfg(0.01, 0.5, 0.5, True))
+    o_losses = oracle.train(2.5e-4, 0.1, f(ro["obs"]), f(rets), f(ro["dones"]), f(ro["actions"]), f(ro["values"]),
+                            f(advs_tm), f(ro["neglogpacs"]), states=ro["states"][envs])
+    theta = dev(util.flatten_params(params, spec))
+    grads = torch.full((spec.nparams,), float("nan"), device="cuda")
+    losses = torch.zeros(8, device="cuda")
+    ws = torch.empty(spec.grad_workspace_bytes(B), dtype=torch.uint8, device="cuda")
+    rref = hip.RolloutRef(spec, dev(ro["obs"]), dev(ro["actions"]), dev(rets), dev(ro["values"]), dev(ro["neglogpacs"]),
+                          dev(advs_tm), T, E, masks=dev(ro["dones"]), states=dev(ro["states"]))
+    d_idx = dev(flat)
+    stats = hip.adv_stats(rref.keep[5], d_idx, B, 1, T, E)
+    hip.ppo_grad(spec, _lib.LossDesc(0.01, 0.5, 0.5, 1), theta, rref, d_idx, B, stats, 0.1, 1.0 / B, grads, losses, ws,
+                 mb_envs=dev(envs), nsteps_mb=T)
+    _check(hip, spec, params, oracle, o_losses, theta, grads, losses)
+    # single-step forward with state hand-over, as Runner.run drives it
+    fws = torch.empty(spec.forward_workspace_bytes(E), dtype=torch.uint8, device="cuda")
+    th = dev(util.flatten_params(params, spec))
+    pi, vf, snew = hip.policy_forward(spec, th, dev(ro["obs"][0]), fws, masks=dev(ro["dones"][0]), states=dev(ro["states"]))
+    p = tfgraph.to_torch(params, torch.float64, requires_grad=False)
+    o_pi, o_vf, o_s = tfgraph.cnn_lstm_forward(p, torch.as_tensor(ro["obs"][0]), torch.as_tensor(ro["dones"][0].astype(np.float64)),
+                                               torch.as_tensor(ro["states"]).double(), E, 1)
+    np.testing.assert_allclose(pi.cpu().numpy(), o_pi.numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(snew.cpu().numpy(), o_s.numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_lnlstm_is_refused_not_faked(hip):
+    from baselines_amd import _lib
+    spec = hip.PolicySpec(_lib.POLICY_CNN_LNLSTM, _lib.DIST_CATEGORICAL, 4, 1, ob_hwc=(36, 36, 2), nlstm=32)
+    assert spec.forward_workspace_bytes(4) == 0
+    with pytest.raises((ValueError, _lib.Ppo2HipError)):
+        hip.policy_forward(spec, torch.zeros(spec.nparams, device="cuda"), torch.zeros((4, 36, 36, 2), dtype=torch.uint8, device="cuda"),
+                           torch.empty(256, dtype=torch.uint8, device="cuda"), masks=torch.zeros(4, dtype=torch.uint8, device="cuda"),
+                           states=torch.zeros((4, 64), device="cuda"))

@@ -63,3 +63,44 @@ def synthetic_mlp_rollout(rng, T, E, D, A, R, gaussian, params, nlp_noise=0.3):
     last_dones = rng.rand(E) < 0.05
     return dict(obs=obs, actions=actions, neglogpacs=nlp, values=values, rewards=rewards, dones=dones,
                 last_values=last_values, last_dones=last_dones)
+
+
+def conv_out(n, k, s):
+    return (n - k) // s + 1
+
+
+def cnn_flat(H, W):
+    h, w = conv_out(conv_out(conv_out(H, 8, 4), 4, 2), 3, 1), conv_out(conv_out(conv_out(W, 8, 4), 4, 2), 3, 1)
+    return h * w * 64
+
+
+def synthetic_cnn_rollout(rng, T, E, hwc, nact, params, kind="cnn", nlstm=0, nlp_noise=0.2):
+    """uint8 image rollout; actions / values / neglogpacs from `params` (recurrent policies are
+    stepped through time with done-mask resets, as the runner would)."""
+    import torch
+    H, W, C = hwc
+    obs = rng.randint(0, 256, size=(T, E, H, W, C)).astype(np.uint8)
+    dones = rng.rand(T, E) < 0.1
+    p = tfgraph.to_torch(params, torch.float64, requires_grad=False)
+    actions = np.zeros((T, E), np.int32)
+    values = np.zeros((T, E, 1), np.float32)
+    nlp = np.zeros((T, E), np.float32)
+    state = np.zeros((E, 2 * nlstm), np.float32) if nlstm else None
+    states0 = None if state is None else state.copy()
+    with torch.no_grad():
+        for t in range(T):
+            if kind == "cnn":
+                pi, vf = tfgraph.cnn_forward(p, torch.as_tensor(obs[t]))
+            else:
+                pi, vf, snew = tfgraph.cnn_lstm_forward(p, torch.as_tensor(obs[t]), torch.as_tensor(dones[t].astype(np.float64)),
+                                                        torch.as_tensor(state).double(), E, 1, layer_norm=(kind == "lnlstm"))
+                state = snew.numpy().astype(np.float32)
+            pi = pi.numpy()
+            u = rng.rand(E, nact)
+            a = np.argmax(pi - np.log(-np.log(u)), axis=1).astype(np.int32)
+            actions[t] = a
+            values[t, :, 0] = vf.numpy()[:, 0] + 0.3 * rng.randn(E)
+            nlp[t] = tfgraph.categorical_neglogp(torch.as_tensor(pi), torch.as_tensor(a)).numpy() + nlp_noise * rng.randn(E)
+    rewards = rng.randn(T, E, 1).astype(np.float32)
+    return dict(obs=obs, actions=actions, neglogpacs=nlp, values=values, rewards=rewards, dones=dones,
+                last_values=rng.randn(E, 1).astype(np.float32), last_dones=rng.rand(E) < 0.1, states=states0)
