@@ -21,15 +21,27 @@ __global__ void sumsq_partial_kernel(const float *__restrict__ g, int64_t P, flo
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
+// npartial == 0 with clipping on: the arena is small, so every block sums the squares of the
+// WHOLE gradient itself (same order in every block, hence the same norm) and no separate
+// norm launch is needed.
 __global__ void adam_kernel(float *__restrict__ theta, const float *__restrict__ g, float *__restrict__ m,
                             float *__restrict__ v, int64_t P, float a, float beta1, float beta2, float eps,
                             float gscale, float max_norm, const double *__restrict__ partial, int npartial,
                             float *__restrict__ header) {
     __shared__ float scale_s;
+    __shared__ double red[17];
+    double own = 0.0;
+    if (max_norm > 0.f && npartial == 0) {
+        for (int64_t i = threadIdx.x; i < P; i += blockDim.x) {
+            const double x = (double)(g[i] * gscale);
+            own += x * x;
+        }
+        own = block_sum(own, red);
+    }
     if (threadIdx.x == 0) {
         float scale = gscale;
         if (max_norm > 0.f) {
-            double ss = 0.0;
+            double ss = own;
             for (int b = 0; b < npartial; b++) ss += partial[b];
             const float norm = (float)sqrt(ss);
             scale = gscale * (max_norm / fmaxf(norm, max_norm));
@@ -70,7 +82,7 @@ extern "C" int ppo2hip_adam_step(float *params, const float *grads, float *m, fl
     float *header = (float *)scratch;
     double *partial = (double *)((char *)scratch + kScratchHeader);
     int npartial = 0;
-    if (max_grad_norm > 0.0) {
+    if (max_grad_norm > 0.0 && P > 65536) {
         npartial = (int)(ceil_div(P, 1024) < kNormBlocks ? ceil_div(P, 1024) : kNormBlocks);
         hipLaunchKernelGGL(sumsq_partial_kernel, dim3(npartial), dim3(256), 0, s, grads, P, (float)grad_scale, partial);
         int rc = check_launch("sumsq_partial_kernel");

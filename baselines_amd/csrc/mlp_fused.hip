@@ -518,69 +518,84 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mlp_fused_kernel(FusedArgs g
     }
 }
 
-// grads[dst + e] = sum_z slabs[(base + z) * slab_elems + src + e] for a table of segments
+// One launch finishes a minibatch gradient: block ranges [0, nseg) sum the trunk matrices out
+// of the per-workgroup slabs, [nseg, nseg + nhead) the head matrices (32-column image rows ->
+// O-column arena rows), and the last block turns the loss partial rows into the five reported
+// scalars and the logstd gradient.  Every sum runs in a fixed order.
 struct SegTable {
     int n;
     int64_t src[8], dst[8], size[8];
     int trunk[8];
 };
+struct FinalizeArgs {
+    const float *slabs;
+    int nslabs;
+    int64_t slab_elems;
+    SegTable t;
+    int nseg_blocks, nhead_blocks;
+    int s_wh, s_bh, H2, A, R;
+    int64_t a_dst, v_dst;
+    float *grads;
+    const double *loss_partial;
+    int nloss_rows, A_gaussian;
+    double inv_count;
+    float *losses, *dlogstd;
+};
 
-__global__ __launch_bounds__(256) void reduce_segments_kernel(const float *__restrict__ slabs, int nslabs,
-                                                              int64_t slab_elems, SegTable t, float *__restrict__ dst) {
+__global__ __launch_bounds__(256) void fused_finalize_kernel(FinalizeArgs f) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    int64_t e = (int64_t)blockIdx.x * 64 + lane;
-    // segments are padded to multiples of 64 elements in the block index space
-    int seg = 0;
-    int64_t base = 0;
-    for (; seg < t.n; seg++) {
-        const int64_t padded = (t.size[seg] + 63) / 64 * 64;
-        if ((int64_t)blockIdx.x * 64 < base + padded) break;
-        base += padded;
+    const int b = blockIdx.x;
+    if (b < f.nseg_blocks + f.nhead_blocks) {
+        const float *p = nullptr;
+        float *out = nullptr;
+        if (b < f.nseg_blocks) {
+            int seg = 0;
+            int64_t base = 0;
+            for (; seg < f.t.n; seg++) {
+                const int64_t padded = (f.t.size[seg] + 63) / 64 * 64;
+                if ((int64_t)b * 64 < base + padded) break;
+                base += padded;
+            }
+            const int64_t e = (int64_t)b * 64 + lane - base;
+            if (seg < f.t.n && e < f.t.size[seg]) {
+                p = f.slabs + (int64_t)f.t.trunk[seg] * f.nslabs * f.slab_elems + f.t.src[seg] + e;
+                out = f.grads + f.t.dst[seg] + e;
+            }
+        } else {
+            const int hb = b - f.nseg_blocks;
+            const int na = (f.H2 + 1) * f.A, nv = (f.H2 + 1) * f.R;
+            const int nba = (na + 63) / 64;
+            const int trunk = hb >= nba ? 1 : 0;
+            const int e = (hb - (trunk ? nba : 0)) * 64 + lane;
+            const int O = trunk ? f.R : f.A;
+            if (e < (trunk ? nv : na)) {
+                const int k = e / O, o = e - k * O;
+                const int src = k < f.H2 ? f.s_wh + k * 32 + o : f.s_bh + o;
+                p = f.slabs + (int64_t)trunk * f.nslabs * f.slab_elems + src;
+                out = f.grads + (trunk ? f.v_dst : f.a_dst) + e;
+            }
+        }
+        float s = 0.f;
+        if (p)
+            for (int z = grp; z < f.nslabs; z += 4) s += p[(int64_t)z * f.slab_elems];
+        part[grp][lane] = s;
+        __syncthreads();
+        if (grp == 0 && out) *out = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        return;
     }
-    if (seg >= t.n) return;
-    e -= base;
-    const bool ok = e < t.size[seg];
-    float s = 0.f;
-    if (ok) {
-        const float *p = slabs + (int64_t)t.trunk[seg] * nslabs * slab_elems + t.src[seg] + e;
-        for (int z = grp; z < nslabs; z += 4) s += p[(int64_t)z * slab_elems];
+    // loss scalars + logstd gradient: one wave per output
+    const int nout = 8 + f.A_gaussian;
+    for (int j = grp; j < nout; j += 4) {
+        double s = 0.0;
+        if (j < 5 || j >= 8)
+            for (int r = lane; r < f.nloss_rows; r += 64) s += f.loss_partial[(int64_t)r * kLossStride + j];
+        s = wave_sum(s);
+        if (lane == 0) {
+            if (j < 8) f.losses[j] = (float)(s * f.inv_count);
+            else if (f.dlogstd) f.dlogstd[j - 8] = (float)s;
+        }
     }
-    part[grp][lane] = s;
-    __syncthreads();
-    if (grp == 0 && ok) dst[t.dst[seg] + e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-}
-
-// head matrices: the slab image keeps 32 columns per row, the arena O columns
-__global__ __launch_bounds__(256) void reduce_heads_kernel(const float *__restrict__ slabs, int nslabs,
-                                                           int64_t slab_elems, int s_wh, int s_bh, int H2, int A,
-                                                           int64_t a_dst, int R, int64_t v_dst, float *__restrict__ dst) {
-    __shared__ float part[4][64];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int na = (H2 + 1) * A, nv = (H2 + 1) * R;
-    const int nba = (na + 63) / 64;
-    const int trunk = (int)blockIdx.x >= nba ? 1 : 0;
-    const int e = ((int)blockIdx.x - (trunk ? nba : 0)) * 64 + lane;
-    const int O = trunk ? R : A;
-    const bool ok = e < (trunk ? nv : na);
-    float s = 0.f;
-    if (ok) {
-        const int k = e / O, o = e - k * O;
-        const int src = k < H2 ? s_wh + k * 32 + o : s_bh + o;
-        const float *p = slabs + (int64_t)trunk * nslabs * slab_elems + src;
-        for (int z = grp; z < nslabs; z += 4) s += p[(int64_t)z * slab_elems];
-    }
-    part[grp][lane] = s;
-    __syncthreads();
-    if (grp == 0 && ok) dst[(trunk ? v_dst : a_dst) + e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-}
-
-static int fused_head_reduce(const float *slabs, int nslabs, int64_t slab_elems, int s_wh, int s_bh, int H2, int A,
-                             int64_t a_dst, int R, int64_t v_dst, float *grads, hipStream_t s) {
-    const int blocks = ((H2 + 1) * A + 63) / 64 + ((H2 + 1) * R + 63) / 64;
-    hipLaunchKernelGGL(reduce_heads_kernel, dim3(blocks), dim3(256), 0, s, slabs, nslabs, slab_elems, s_wh, s_bh, H2, A,
-                       a_dst, R, v_dst, grads);
-    return check_launch("reduce_heads_kernel");
 }
 
 bool mlp_fused_supported(const ppo2hip_policy_desc &d) {
@@ -629,27 +644,28 @@ int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, co
     if (rc) return rc;
 
     const int H1 = 64, H2 = 64, D = d.ob_dim, A = d.ac_dim, R = d.nvalue;
-    SegTable t;
-    t.n = 0;
+    FinalizeArgs fa;
+    fa.t.n = 0;
     auto seg = [&](int trunk, int64_t src, int64_t dst, int64_t size) {
+        SegTable &t = fa.t;
         t.trunk[t.n] = trunk; t.src[t.n] = src; t.dst[t.n] = dst; t.size[t.n] = size; t.n++;
     };
-    int64_t blocks = 0;
     for (int trunk = 0; trunk < 2; trunk++) {
         const int64_t w1 = trunk ? fo.v_w1 : fo.a_w1, w2 = trunk ? fo.v_w2 : fo.a_w2;
         seg(trunk, L::S_W1, w1, (int64_t)(D + 1) * H1);            // w1 rows + bias row, contiguous in the arena
         seg(trunk, L::S_W2, w2, (int64_t)H1 * H2 + H2);            // w2 then b2 (adjacent in image and arena)
     }
-    rc = 0;
-    for (int i = 0; i < t.n; i++) blocks += (t.size[i] + 63) / 64;
-    hipLaunchKernelGGL(reduce_segments_kernel, dim3((unsigned)blocks), dim3(256), 0, s, slabs, grid / 2,
-                       (int64_t)L::SLAB, t, grads);
-    if ((rc = check_launch("reduce_segments_kernel"))) return rc;
-    // heads: the image keeps 32 columns per row, the arena O columns -> dedicated small kernel
-    rc = fused_head_reduce(slabs, grid / 2, L::SLAB, L::S_WH, L::S_BH, H2, A, fo.a_wh, R, fo.v_wh, grads, s);
-    if (rc) return rc;
-    return loss_final(lpart, grid, d.dist == PPO2HIP_DIST_GAUSSIAN ? A : 0, inv_count, losses,
-                      d.dist == PPO2HIP_DIST_GAUSSIAN ? grads + fo.logstd : nullptr, s);
+    int64_t blocks = 0;
+    for (int i = 0; i < fa.t.n; i++) blocks += (fa.t.size[i] + 63) / 64;
+    const bool gauss = d.dist == PPO2HIP_DIST_GAUSSIAN;
+    fa.slabs = slabs; fa.nslabs = grid / 2; fa.slab_elems = L::SLAB;
+    fa.nseg_blocks = (int)blocks;
+    fa.nhead_blocks = ((H2 + 1) * A + 63) / 64 + ((H2 + 1) * R + 63) / 64;
+    fa.s_wh = L::S_WH; fa.s_bh = L::S_BH; fa.H2 = H2; fa.A = A; fa.R = R; fa.a_dst = fo.a_wh; fa.v_dst = fo.v_wh;
+    fa.grads = grads; fa.loss_partial = lpart; fa.nloss_rows = grid; fa.A_gaussian = gauss ? A : 0;
+    fa.inv_count = inv_count; fa.losses = losses; fa.dlogstd = gauss ? grads + fo.logstd : nullptr;
+    hipLaunchKernelGGL(fused_finalize_kernel, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(256), 0, s, fa);
+    return check_launch("fused_finalize_kernel");
 }
 
 }  // namespace ppo2hip
