@@ -82,6 +82,20 @@ int loss_final(const double *partial, int nblocks, int A_gaussian, double inv_co
 struct FusedOffsets {
     int64_t a_w1, a_w2, a_wh, v_w1, v_w2, v_wh, logstd;   // offsets of the (w, b) pairs / logstd in the arena
 };
+// where a fused kernel's per-workgroup gradient image keeps each block, and the head's row width
+struct FusedImage {
+    int64_t slab_elems;
+    int s_w1, s_w2, s_wh, s_bh, head_cols;
+};
+int fused_finalize(const FusedImage &im, const float *slabs, int nslabs, const double *lpart, int nloss_rows,
+                   const ppo2hip_policy_desc &d, const FusedOffsets &fo, double inv_count, float *grads, float *losses,
+                   hipStream_t s);
+bool mlp_fused16_supported(const ppo2hip_policy_desc &d);
+size_t mlp_fused16_workspace_bytes();
+int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params,
+                     const FusedOffsets &fo, const ppo2hip_rollout &ro, const int32_t *idx, int64_t B,
+                     const double *stats, float cliprange, double inv_count, float *grads, float *losses, void *ws,
+                     size_t ws_bytes, hipStream_t s);
 bool mlp_fused_supported(const ppo2hip_policy_desc &d);
 size_t mlp_fused_workspace_bytes();
 int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params,

@@ -533,7 +533,7 @@ struct FinalizeArgs {
     int64_t slab_elems;
     SegTable t;
     int nseg_blocks, nhead_blocks;
-    int s_wh, s_bh, H2, A, R;
+    int s_wh, s_bh, H2, A, R, head_cols;
     int64_t a_dst, v_dst;
     float *grads;
     const double *loss_partial;
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void fused_finalize_kernel(FinalizeArgs f) {
             const int O = trunk ? f.R : f.A;
             if (e < (trunk ? nv : na)) {
                 const int k = e / O, o = e - k * O;
-                const int src = k < f.H2 ? f.s_wh + k * 32 + o : f.s_bh + o;
+                const int src = k < f.H2 ? f.s_wh + k * f.head_cols + o : f.s_bh + o;
                 p = f.slabs + (int64_t)trunk * f.nslabs * f.slab_elems + src;
                 out = f.grads + (trunk ? f.v_dst : f.a_dst) + e;
             }
@@ -596,6 +596,35 @@ __global__ __launch_bounds__(256) void fused_finalize_kernel(FinalizeArgs f) {
             else if (f.dlogstd) f.dlogstd[j - 8] = (float)s;
         }
     }
+}
+
+int fused_finalize(const FusedImage &im, const float *slabs, int nslabs, const double *lpart, int nloss_rows,
+                   const ppo2hip_policy_desc &d, const FusedOffsets &fo, double inv_count, float *grads, float *losses,
+                   hipStream_t s) {
+    const int H1 = d.hidden1, H2 = d.hidden2, D = d.ob_dim, A = d.ac_dim, R = d.nvalue;
+    FinalizeArgs fa;
+    fa.t.n = 0;
+    auto seg = [&](int trunk, int64_t src, int64_t dst, int64_t size) {
+        SegTable &t = fa.t;
+        t.trunk[t.n] = trunk; t.src[t.n] = src; t.dst[t.n] = dst; t.size[t.n] = size; t.n++;
+    };
+    for (int trunk = 0; trunk < 2; trunk++) {
+        const int64_t w1 = trunk ? fo.v_w1 : fo.a_w1, w2 = trunk ? fo.v_w2 : fo.a_w2;
+        seg(trunk, im.s_w1, w1, (int64_t)(D + 1) * H1);            // w1 rows + bias row, contiguous in the arena
+        seg(trunk, im.s_w2, w2, (int64_t)H1 * H2 + H2);            // w2 then b2 (adjacent in image and arena)
+    }
+    int64_t blocks = 0;
+    for (int i = 0; i < fa.t.n; i++) blocks += (fa.t.size[i] + 63) / 64;
+    const bool gauss = d.dist == PPO2HIP_DIST_GAUSSIAN;
+    fa.slabs = slabs; fa.nslabs = nslabs; fa.slab_elems = im.slab_elems;
+    fa.nseg_blocks = (int)blocks;
+    fa.nhead_blocks = ((H2 + 1) * A + 63) / 64 + ((H2 + 1) * R + 63) / 64;
+    fa.s_wh = im.s_wh; fa.s_bh = im.s_bh; fa.H2 = H2; fa.A = A; fa.R = R; fa.head_cols = im.head_cols;
+    fa.a_dst = fo.a_wh; fa.v_dst = fo.v_wh;
+    fa.grads = grads; fa.loss_partial = lpart; fa.nloss_rows = nloss_rows; fa.A_gaussian = gauss ? A : 0;
+    fa.inv_count = inv_count; fa.losses = losses; fa.dlogstd = gauss ? grads + fo.logstd : nullptr;
+    hipLaunchKernelGGL(fused_finalize_kernel, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(256), 0, s, fa);
+    return check_launch("fused_finalize_kernel");
 }
 
 bool mlp_fused_supported(const ppo2hip_policy_desc &d) {
@@ -643,29 +672,9 @@ int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, co
     int rc = check_launch("mlp_fused_kernel");
     if (rc) return rc;
 
-    const int H1 = 64, H2 = 64, D = d.ob_dim, A = d.ac_dim, R = d.nvalue;
-    FinalizeArgs fa;
-    fa.t.n = 0;
-    auto seg = [&](int trunk, int64_t src, int64_t dst, int64_t size) {
-        SegTable &t = fa.t;
-        t.trunk[t.n] = trunk; t.src[t.n] = src; t.dst[t.n] = dst; t.size[t.n] = size; t.n++;
-    };
-    for (int trunk = 0; trunk < 2; trunk++) {
-        const int64_t w1 = trunk ? fo.v_w1 : fo.a_w1, w2 = trunk ? fo.v_w2 : fo.a_w2;
-        seg(trunk, L::S_W1, w1, (int64_t)(D + 1) * H1);            // w1 rows + bias row, contiguous in the arena
-        seg(trunk, L::S_W2, w2, (int64_t)H1 * H2 + H2);            // w2 then b2 (adjacent in image and arena)
-    }
-    int64_t blocks = 0;
-    for (int i = 0; i < fa.t.n; i++) blocks += (fa.t.size[i] + 63) / 64;
-    const bool gauss = d.dist == PPO2HIP_DIST_GAUSSIAN;
-    fa.slabs = slabs; fa.nslabs = grid / 2; fa.slab_elems = L::SLAB;
-    fa.nseg_blocks = (int)blocks;
-    fa.nhead_blocks = ((H2 + 1) * A + 63) / 64 + ((H2 + 1) * R + 63) / 64;
-    fa.s_wh = L::S_WH; fa.s_bh = L::S_BH; fa.H2 = H2; fa.A = A; fa.R = R; fa.a_dst = fo.a_wh; fa.v_dst = fo.v_wh;
-    fa.grads = grads; fa.loss_partial = lpart; fa.nloss_rows = grid; fa.A_gaussian = gauss ? A : 0;
-    fa.inv_count = inv_count; fa.losses = losses; fa.dlogstd = gauss ? grads + fo.logstd : nullptr;
-    hipLaunchKernelGGL(fused_finalize_kernel, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(256), 0, s, fa);
-    return check_launch("fused_finalize_kernel");
+    FusedImage im;
+    im.slab_elems = L::SLAB; im.s_w1 = L::S_W1; im.s_w2 = L::S_W2; im.s_wh = L::S_WH; im.s_bh = L::S_BH; im.head_cols = 32;
+    return fused_finalize(im, slabs, grid / 2, lpart, grid, d, fo, inv_count, grads, losses, s);
 }
 
 }  // namespace ppo2hip

@@ -152,7 +152,9 @@ static void carve_mlp(const ppo2hip_policy_desc &d, int64_t B, Carver &c, MlpBuf
     w.slab_elems = se;
     w.slabs = c.take<float>(se);
     w.loss_partial = c.take<double>((int64_t)loss_partial_blocks(B) * 80);
-    w.fused_bytes = mlp_fused_supported(d) ? mlp_fused_workspace_bytes() : 0;
+    w.fused_bytes = 0;
+    if (mlp_fused_supported(d)) w.fused_bytes = mlp_fused_workspace_bytes();
+    if (mlp_fused16_supported(d) && mlp_fused16_workspace_bytes() > w.fused_bytes) w.fused_bytes = mlp_fused16_workspace_bytes();
     w.fused = c.take<char>(w.fused_bytes);
 }
 
@@ -190,11 +192,15 @@ static int mlp_trunk_backward(const float *X, int D, const float *H1, int h1, co
     return 0;
 }
 
-// PPO2HIP_MLP_PATH=layered selects the layer-by-layer GEMM path for shapes the fused kernel
-// also covers (the two are checked against each other in the tests)
-static bool layered_forced() {
+// PPO2HIP_MLP_PATH = layered | fused32 | fused16 pins one of the routes for shapes that several
+// cover (the tests check them against each other); default: the fastest that supports the shape.
+static int mlp_path_choice(const ppo2hip_policy_desc &d) {
     const char *e = getenv("PPO2HIP_MLP_PATH");
-    return e && std::strcmp(e, "layered") == 0;
+    const bool f16 = mlp_fused16_supported(d), f32 = mlp_fused_supported(d);
+    if (e && std::strcmp(e, "layered") == 0) return 0;
+    if (e && std::strcmp(e, "fused32") == 0 && f32) return 32;
+    if (e && std::strcmp(e, "fused16") == 0 && f16) return 16;
+    return f16 ? 16 : (f32 ? 32 : 0);
 }
 
 static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const Layout &L, const float *p,
@@ -209,9 +215,13 @@ static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
     }
     const int D = d.ob_dim, h1 = d.hidden1, h2 = d.hidden2, A = d.ac_dim, R = d.nvalue;
     const bool gauss = d.dist == PPO2HIP_DIST_GAUSSIAN;
-    if (mlp_fused_supported(d) && !layered_forced()) {
+    const int path = mlp_path_choice(d);
+    if (path) {
         FusedOffsets fo{L.off("pi_fc1/w"), L.off("pi_fc2/w"), L.off("pi/w"), L.off("vf_fc1/w"), L.off("vf_fc2/w"),
                         L.off("vf/w"), gauss ? L.off("logstd") : 0};
+        if (path == 16)
+            return mlp_fused16_grad(d, lc, p, fo, ro, idx, B, stats, cliprange, inv_count, grads, losses, w.fused,
+                                    w.fused_bytes, s);
         return mlp_fused_grad(d, lc, p, fo, ro, idx, B, stats, cliprange, inv_count, grads, losses, w.fused,
                               w.fused_bytes, s);
     }

@@ -181,17 +181,19 @@ def test_fused_and_layered_mlp_paths_agree(hip, cfg, monkeypatch):
                           dev(ro["neglogpacs"]), dev(advs_tm), T, E)
     stats = hip.adv_stats(rref.keep[5], idx, B, 1, T, E)
     out = {}
-    for path in ("fused", "layered"):
+    for path in ("fused16", "fused32", "layered"):
         monkeypatch.setenv("PPO2HIP_MLP_PATH", path)
         grads = torch.full((spec.nparams,), float("nan"), device="cuda")
         losses = torch.zeros(8, device="cuda")
         hip.ppo_grad(spec, lossd, theta, rref, idx, B, stats, 0.2, 1.0 / B, grads, losses, ws)
         torch.cuda.synchronize()
         out[path] = (grads.cpu().numpy(), losses.cpu().numpy())
-    gf, gl = out["fused"][0], out["layered"][0]
-    assert np.all(np.isfinite(gf))
-    np.testing.assert_allclose(out["fused"][1][:5], out["layered"][1][:5], rtol=2e-5, atol=1e-7)
-    for name, off, shp in spec.vars:
-        n = int(np.prod(shp))
-        a, b = gf[off:off + n], gl[off:off + n]
-        assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-6), (name, np.abs(a - b).max(), np.abs(b).max())
+    gl = out["layered"][0]
+    for path in ("fused16", "fused32"):
+        gf = out[path][0]
+        assert np.all(np.isfinite(gf))
+        np.testing.assert_allclose(out[path][1][:5], out["layered"][1][:5], rtol=2e-5, atol=1e-7)
+        for name, off, shp in spec.vars:
+            n = int(np.prod(shp))
+            a, b = gf[off:off + n], gl[off:off + n]
+            assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-6), (path, name, np.abs(a - b).max(), np.abs(b).max())
