@@ -32,7 +32,7 @@ class LossDesc(Structure):
 class Rollout(Structure):
     _fields_ = [("obs", c_void_p), ("actions", c_void_p), ("returns", c_void_p), ("values", c_void_p),
                 ("neglogpacs", c_void_p), ("advs", c_void_p), ("masks", c_void_p), ("states", c_void_p),
-                ("adv_f64", c_int32), ("T", c_int32), ("E", c_int32)]
+                ("adv_f64", c_int32), ("T", c_int32), ("E", c_int32), ("_pad", c_int32), ("n", c_int64)]
 
 
 class Ppo2HipError(RuntimeError):

@@ -86,11 +86,14 @@ struct FusedOffsets {
 struct FusedImage {
     int64_t slab_elems;
     int s_w1, s_w2, s_wh, s_bh, head_cols;
+    int s_logstd;   // where the image holds the summed logstd gradient, or -1: it is in the loss partial rows
 };
 int fused_finalize(const FusedImage &im, const float *slabs, int nslabs, const double *lpart, int nloss_rows,
                    const ppo2hip_policy_desc &d, const FusedOffsets &fo, double inv_count, float *grads, float *losses,
                    hipStream_t s);
 bool mlp_fused16_supported(const ppo2hip_policy_desc &d);
+// every rollout array and the index list stay under 4 GB (the kernel addresses them with 32-bit byte offsets)
+bool mlp_fused16_fits(const ppo2hip_policy_desc &d, const ppo2hip_rollout &ro, int64_t B);
 size_t mlp_fused16_workspace_bytes();
 int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params,
                      const FusedOffsets &fo, const ppo2hip_rollout &ro, const int32_t *idx, int64_t B,

@@ -533,7 +533,7 @@ struct FinalizeArgs {
     int64_t slab_elems;
     SegTable t;
     int nseg_blocks, nhead_blocks;
-    int s_wh, s_bh, H2, A, R, head_cols;
+    int s_wh, s_bh, s_logstd, H2, A, R, head_cols;
     int64_t a_dst, v_dst;
     float *grads;
     const double *loss_partial;
@@ -542,8 +542,10 @@ struct FinalizeArgs {
     float *losses, *dlogstd;
 };
 
-__global__ __launch_bounds__(256) void fused_finalize_kernel(FinalizeArgs f) {
-    __shared__ float part[4][64];
+constexpr int kFinGroups = 16;   // slab groups per block: 1024 threads, every lane a handful of independent loads
+
+__global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(FinalizeArgs f) {
+    __shared__ float part[kFinGroups][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int b = blockIdx.x;
     if (b < f.nseg_blocks + f.nhead_blocks) {
@@ -563,9 +565,12 @@ __global__ __launch_bounds__(256) void fused_finalize_kernel(FinalizeArgs f) {
                 out = f.grads + f.t.dst[seg] + e;
             }
         } else {
+            // head matrices (image rows of head_cols columns -> O-column arena rows, bias row last), then
+            // for the policy trunk the logstd gradient when the kernel summed it inside the bias image
             const int hb = b - f.nseg_blocks;
+            const int nls = f.s_logstd >= 0 ? f.A_gaussian : 0;
             const int na = (f.H2 + 1) * f.A, nv = (f.H2 + 1) * f.R;
-            const int nba = (na + 63) / 64;
+            const int nba = (na + nls + 63) / 64;
             const int trunk = hb >= nba ? 1 : 0;
             const int e = (hb - (trunk ? nba : 0)) * 64 + lane;
             const int O = trunk ? f.R : f.A;
@@ -574,19 +579,27 @@ __global__ __launch_bounds__(256) void fused_finalize_kernel(FinalizeArgs f) {
                 const int src = k < f.H2 ? f.s_wh + k * f.head_cols + o : f.s_bh + o;
                 p = f.slabs + (int64_t)trunk * f.nslabs * f.slab_elems + src;
                 out = f.grads + (trunk ? f.v_dst : f.a_dst) + e;
+            } else if (!trunk && e < na + nls) {
+                p = f.slabs + f.s_logstd + (e - na);
+                out = f.dlogstd + (e - na);
             }
         }
         float s = 0.f;
         if (p)
-            for (int z = grp; z < f.nslabs; z += 4) s += p[(int64_t)z * f.slab_elems];
+            for (int z = grp; z < f.nslabs; z += kFinGroups) s += p[(int64_t)z * f.slab_elems];
         part[grp][lane] = s;
         __syncthreads();
-        if (grp == 0 && out) *out = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (grp == 0 && out) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < kFinGroups; q++) t += part[q][lane];
+            *out = t;
+        }
         return;
     }
-    // loss scalars + logstd gradient: one wave per output
-    const int nout = 8 + f.A_gaussian;
-    for (int j = grp; j < nout; j += 4) {
+    // loss scalars (+ the logstd gradient when it travels in the loss partial rows): one wave per output
+    const int nout = 8 + (f.s_logstd < 0 ? f.A_gaussian : 0);
+    for (int j = grp; j < nout; j += kFinGroups) {
         double s = 0.0;
         if (j < 5 || j >= 8)
             for (int r = lane; r < f.nloss_rows; r += 64) s += f.loss_partial[(int64_t)r * kLossStride + j];
@@ -618,12 +631,12 @@ int fused_finalize(const FusedImage &im, const float *slabs, int nslabs, const d
     const bool gauss = d.dist == PPO2HIP_DIST_GAUSSIAN;
     fa.slabs = slabs; fa.nslabs = nslabs; fa.slab_elems = im.slab_elems;
     fa.nseg_blocks = (int)blocks;
-    fa.nhead_blocks = ((H2 + 1) * A + 63) / 64 + ((H2 + 1) * R + 63) / 64;
-    fa.s_wh = im.s_wh; fa.s_bh = im.s_bh; fa.H2 = H2; fa.A = A; fa.R = R; fa.head_cols = im.head_cols;
+    fa.nhead_blocks = ((H2 + 1) * A + (gauss && im.s_logstd >= 0 ? A : 0) + 63) / 64 + ((H2 + 1) * R + 63) / 64;
+    fa.s_wh = im.s_wh; fa.s_bh = im.s_bh; fa.s_logstd = im.s_logstd; fa.H2 = H2; fa.A = A; fa.R = R; fa.head_cols = im.head_cols;
     fa.a_dst = fo.a_wh; fa.v_dst = fo.v_wh;
     fa.grads = grads; fa.loss_partial = lpart; fa.nloss_rows = nloss_rows; fa.A_gaussian = gauss ? A : 0;
     fa.inv_count = inv_count; fa.losses = losses; fa.dlogstd = gauss ? grads + fo.logstd : nullptr;
-    hipLaunchKernelGGL(fused_finalize_kernel, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(256), 0, s, fa);
+    hipLaunchKernelGGL(fused_finalize_kernel, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(64 * kFinGroups), 0, s, fa);
     return check_launch("fused_finalize_kernel");
 }
 
@@ -673,7 +686,7 @@ int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, co
     if (rc) return rc;
 
     FusedImage im;
-    im.slab_elems = L::SLAB; im.s_w1 = L::S_W1; im.s_w2 = L::S_W2; im.s_wh = L::S_WH; im.s_bh = L::S_BH; im.head_cols = 32;
+    im.slab_elems = L::SLAB; im.s_w1 = L::S_W1; im.s_w2 = L::S_W2; im.s_wh = L::S_WH; im.s_bh = L::S_BH; im.head_cols = 32; im.s_logstd = -1;
     return fused_finalize(im, slabs, grid / 2, lpart, grid, d, fo, inv_count, grads, losses, s);
 }
 

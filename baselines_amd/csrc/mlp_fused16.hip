@@ -5,18 +5,24 @@
 // baselines/ppo2/common_functions.py:26-63), re-tiled so that TWO waves share every SIMD.
 //
 // Why 16-sample tiles: a wave's per-tile state halves (activations 16 registers per layer,
-// transposed LDS tiles 4.3 KB), which brings a wave under 256 registers and its LDS scratch
-// to 12 KB, so a 512-thread workgroup (8 waves) fits one CU: while one wave of a SIMD waits on
-// LDS or runs tanh / loss VALU work, the other keeps the matrix pipe busy.
+// LDS tiles 11 KB), which brings a wave under 256 registers, so a 512-thread workgroup
+// (8 waves) fits one CU: while one wave of a SIMD waits on LDS or runs tanh / loss VALU work,
+// the other keeps the matrix pipe busy.
 //
 // Mapping (v_mfma_f32_16x16x4_f32, exact fp32 fma chain; lane l: li = l & 15, lk = l >> 4):
 //   operands  A[i = li][k = lk], B[k = lk][j = li];  result  D[row = 4 lk + r][col = li], r = 0..3.
 //   Samples sit on the column (li) axis, units on rows: a layer's accumulator is directly the B
 //   operand of the next product; its register r supplies unit 4 lk + r, so the A operand for
-//   that k-step is the weight row of unit 16 mb + 4 lk + r.  Weight-gradient products contract
-//   over samples and take both operands from per-wave transposed LDS tiles (row stride 17).
-//   LDS row strides are chosen so the two 16-lane halves of a ds_read_b32 group fall on
-//   disjoint banks (stride = 16 mod 32 where rows are 1 apart, = 4 mod 8 where they are 4 apart).
+//   that k-step is the weight row of unit 16 mb + 4 lk + r.
+//
+// LDS images are laid out for 16-byte reads: every weight matrix is stored "packed", the four
+// values one lane feeds to four consecutive products adjacent (one ds_read_b128 per four MFMAs),
+// and the per-wave transposed tiles [unit][16 samples] keep sample s at column
+// 4 ((s & 3) ^ swizzle(row)) + (s >> 2), so a lane's four samples {lk, lk + 4, lk + 8, lk + 12}
+// of a weight-gradient product are one 16-byte chunk, and the XOR (2 on rows 8..15 of every
+// 16) spreads the four 16-lane groups of a ds_read_b128 over distinct 16-byte bank slots.
+// Head rows are permuted (accumulator row 4 lk + r holds output lk + 4 r) so that outputs
+// 0..O-1 occupy the first ceil(O / 4) registers and the input gradient skips the rest.
 #include "gemm_core.hpp"
 #include "kernels.hpp"
 
@@ -30,22 +36,22 @@ constexpr int kThreads = 512;
 constexpr int kWaves = 8;
 constexpr int H = 64;             // both hidden widths
 constexpr int HB = H / 16;        // 16-unit blocks
-constexpr int LDW1 = 80, LDW2 = 68, LDWH = 20, LDWHT = 68, LDX = 34, LDT = 17;
 // weights (floats)
-constexpr int W1 = 0;                          // [32][80]  rows: D inputs, bias row, zeros
-constexpr int W2 = W1 + 32 * LDW1;             // [64][68]  row = input unit
-constexpr int W2T = W2 + H * LDW2;             // [64][68]  row = output unit
-constexpr int B2 = W2T + H * LDW2;             // [64]
-constexpr int WH = B2 + H;                     // [64][20]  row = input unit, 16 output columns
-constexpr int WHT = WH + H * LDWH;             // [16][68]  row = output
-constexpr int BH = WHT + 16 * LDWHT;           // [16]
-constexpr int WEIGHTS = BH + 16;
-// per-wave scratch (floats)
-constexpr int XS = 0;                          // [16 samples][34]
-constexpr int TA = XS + 16 * LDX;              // [64 units][17]
-constexpr int TB = TA + H * LDT;               // [64][17]
-constexpr int TC = TB + H * LDT;               // [16 outputs][17]
-constexpr int WAVE = TC + 16 * LDT;
+constexpr int W1P = 0;                         // [32 inputs][16 li][4 mb]    unit = 16 mb + li; row D = bias
+constexpr int W2P = W1P + 32 * H;              // [16 k4][64 out][4 r]        input unit = 4 k4 + r
+constexpr int W2TP = W2P + H * H;              // [16 j4][64 in][4 r]         output unit = 4 j4 + r
+constexpr int B2 = W2TP + H * H;               // [64]
+constexpr int WHP = B2 + H;                    // [16 k4][16 rows][4 r]       accumulator row -> output (row >> 2) + 4 (row & 3)
+constexpr int WHTP = WHP + H * 16;             // [4 lk][64 units][4 r]       output = lk + 4 r
+constexpr int BHP = WHTP + H * 16;             // [16 rows]
+constexpr int WEIGHTS = BHP + 16;
+// per-wave tiles (floats), all [rows][16 samples] in the swizzled column order
+constexpr int XA = 0;                          // [32 features]   row D = ones, rows above D = zeros
+constexpr int TA = XA + 32 * 16;               // [64 units]      h1, then d(loss)/d(pre-activation 1)
+constexpr int TB = TA + H * 16;                // [64 units]      h2, then d(loss)/d(pre-activation 2)
+constexpr int TC = TB + H * 16;                // [16 outputs]    d(loss)/d(head output)
+constexpr int SPARE = TC + 16 * 16;              // [64] landing zone for masked-off observation stores
+constexpr int WAVE = SPARE + 64;
 constexpr int TOTAL = WEIGHTS + kWaves * WAVE;
 // gradient image of one trunk (floats): [w1 32x64 | w2 64x64 | b2 64 | wh 64x16 | bh 16]
 constexpr int S_W1 = 0;
@@ -55,8 +61,9 @@ constexpr int S_WH = S_B2 + H;
 constexpr int S_BH = S_WH + H * 16;
 constexpr int SLAB = S_BH + 16;
 static_assert(4 * SLAB <= TOTAL, "LDS must hold four gradient images for the cross-wave reduction");
-static_assert(TOTAL * 4 + 256 <= 160 * 1024, "LDS budget");
+static_assert(TOTAL * 4 + 4096 <= 160 * 1024, "LDS budget");
 constexpr int kLossStride = 8 + 64;
+constexpr int kLossVals = 5;
 }  // namespace f16
 
 struct Fused16Args {
@@ -65,6 +72,7 @@ struct Fused16Args {
     const float *returns, *values, *neglogpacs;
     const void *advs;
     int adv_f64, T, E;
+    int64_t n;               // rows in every rollout array
     const int32_t *idx;
     int64_t B;
     const double *stats;
@@ -76,16 +84,34 @@ struct Fused16Args {
     double *loss_partial;    // [gridDim.x][kLossStride]
 };
 
-__device__ inline float fast_tanh16(float x) {
-    // |error| <= ~1e-7 absolute over the whole range (v_exp_f32 / v_rcp_f32 are 1 ulp)
-    const float t = __expf(2.0f * x);
-    return 1.0f - 2.0f * __frcp_rn(t + 1.0f);
+// The rollout arrays are read through buffer descriptors: 32-bit byte offsets (one register per
+// address instead of two) and hardware range checking, so a lane that reads past the last row
+// gets 0 instead of a fault and the loads need no per-lane guards.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_f32(rsrc_t r, unsigned byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ int buf_i32(rsrc_t r, unsigned byte_off) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
 }
 
+__device__ __forceinline__ float fast_tanh16(float x) {
+    // tanh x = 1 - 2 / (exp(2x) + 1); v_exp_f32 and v_rcp_f32 are 1 ulp: |error| <= ~1.5e-7 absolute
+    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+
+// KQ = k-steps of layer 1 (ob_dim + 1 <= 4 KQ; also the observation registers per lane);
+// WIDE = ob_dim + 1 > 16 (second block of dW1 rows)
+template <int KQ, bool WIDE>
 __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Args g) {
     using namespace f16;
-    __shared__ float lds[TOTAL];
-    __shared__ double red[17];
+    __shared__ __attribute__((aligned(16))) float lds[TOTAL];
+    __shared__ double red[kWaves * kLossVals];
+#define LDS4(off) (*(const f32x4 *)(lds + (off)))
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -95,46 +121,61 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
     const int64_t o_w1 = is_value ? g.v_w1 : g.a_w1, o_w2 = is_value ? g.v_w2 : g.a_w2, o_wh = is_value ? g.v_wh : g.a_wh;
     const int D = g.D;
     const int O = is_value ? g.R : g.A;
+    const int nr = (O + 3) >> 2;                      // head registers in use
     const bool gaussian = g.dist == PPO2HIP_DIST_GAUSSIAN;
 
-    // ---- stage this trunk's weights (both orientations where a transposed read is needed) ----
+    // ---- stage this trunk's weights in the packed layouts ------------------------------------
     {
         const float *P = g.params;
-        for (int e = tid; e < 32 * LDW1; e += kThreads) {
-            const int k = e / LDW1, j = e - k * LDW1;
-            float v = 0.f;
-            if (j < H && k <= D) v = P[o_w1 + (int64_t)k * H + j];      // rows 0..D-1 weights, row D = bias
-            lds[W1 + e] = v;
+#pragma unroll
+        for (int u = 0; u < 32 * H / kThreads; u++) {
+            const int e = tid + u * kThreads;
+            const int k = e >> 6, j = e & 63;                              // input row k, unit j (coalesced read)
+            const float v = k <= D ? P[o_w1 + (int64_t)k * H + j] : 0.f;   // rows 0..D-1 weights, row D = bias
+            lds[W1P + k * 64 + (j & 15) * 4 + (j >> 4)] = v;
         }
-        for (int e = tid; e < H * H; e += kThreads) {
+#pragma unroll
+        for (int u = 0; u < H * H / kThreads; u++) {
+            const int e = tid + u * kThreads;
             const int k = e >> 6, j = e & 63;
             const float v = P[o_w2 + e];
-            lds[W2 + k * LDW2 + j] = v;
-            lds[W2T + j * LDW2 + k] = v;
+            lds[W2P + ((k >> 2) * 64 + j) * 4 + (k & 3)] = v;
+            lds[W2TP + ((j >> 2) * 64 + k) * 4 + (j & 3)] = v;
         }
-        for (int e = tid; e < H; e += kThreads) lds[B2 + e] = P[o_w2 + (int64_t)H * H + e];
-        for (int e = tid; e < H * 16; e += kThreads) {
-            const int k = e >> 4, j = e & 15;
-            const float v = j < O ? P[o_wh + (int64_t)k * O + j] : 0.f;
-            lds[WH + k * LDWH + j] = v;
-            lds[WHT + j * LDWHT + k] = v;
+        if (tid < H) lds[B2 + tid] = P[o_w2 + (int64_t)H * H + tid];
+#pragma unroll
+        for (int u = 0; u < H * 16 / kThreads; u++) {
+            const int e = tid + u * kThreads;
+            const int k = e >> 4, o = e & 15;                              // hidden unit k, real output o
+            const float v = o < O ? P[o_wh + (int64_t)k * O + o] : 0.f;
+            const int row = 4 * (o & 3) + (o >> 2);                        // accumulator row of output o
+            lds[WHP + ((k >> 2) * 16 + row) * 4 + (k & 3)] = v;
+            lds[WHTP + ((o & 3) * 64 + k) * 4 + (o >> 2)] = v;
         }
-        for (int e = tid; e < 16; e += kThreads) lds[BH + e] = e < O ? P[o_wh + (int64_t)H * O + e] : 0.f;
+        if (tid < 16) {
+            const int o = (tid >> 2) + 4 * (tid & 3);                      // output held by accumulator row tid
+            lds[BHP + tid] = o < O ? P[o_wh + (int64_t)H * O + o] : 0.f;
+        }
         for (int e = tid; e < kWaves * WAVE; e += kThreads) lds[WEIGHTS + e] = 0.f;
     }
     __syncthreads();
 
-    float *const xs = lds + WEIGHTS + wave * WAVE + XS;
+    float *const xa = lds + WEIGHTS + wave * WAVE + XA;
     float *const ta = lds + WEIGHTS + wave * WAVE + TA;
     float *const tb = lds + WEIGHTS + wave * WAVE + TB;
     float *const tc = lds + WEIGHTS + wave * WAVE + TC;
-    const float *const w1s = lds + W1;
-    const float *const w2s = lds + W2;
-    const float *const w2ts = lds + W2T;
-    const float *const b2s = lds + B2;
-    const float *const whs = lds + WH;
-    const float *const whts = lds + WHT;
-    const float *const bhs = lds + BH;
+    if (lane < 16) xa[D * 16 + lane] = 1.f;            // the ones feature (its column order is irrelevant)
+    __builtin_amdgcn_wave_barrier();
+
+    // lane-constant tile offsets.  Element (row, sample s) of a tile sits at
+    //   row * 16 + 4 ((s & 3) ^ swz(row)) + (s >> 2),   swz(row) = 2 on rows 8..15 of every 16.
+    const int c0 = ((li & 3) << 2) + (li >> 2);                         // sample li in a row with swz 0
+    const int c1 = (((li & 3) ^ 2) << 2) + (li >> 2);                   // ... with swz 2
+    // accumulator element (block m, register r) = unit 16 m + 4 lk + r of sample li: swz = lk & 2
+    const int dpos = 4 * lk * 16 + ((lk & 2) ? c1 : c0);                // + (16 m + r) * 16
+    // 16-byte chunk {samples lk, lk + 4, lk + 8, lk + 12} of row 16 m + li: swz = (li >> 2) & 2
+    const int rpos = li * 16 + ((lk ^ ((li >> 2) & 2)) << 2);           // + 256 m
+    const int wpos = (lk * 64 + li) * 4;                                // lane part of the packed 64-wide weight reads
 
     // advantage normalisation constants (baselines/ppo2/common_functions.py:67)
     double adv_mean = 0.0, adv_rstd = 1.0;
@@ -145,20 +186,30 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
         var = var > 0.0 ? var : 0.0;
         adv_rstd = 1.0 / (sqrt(var) + 1e-8);
     }
-    float inv_std[4] = {0.f, 0.f, 0.f, 0.f};
+    // wave-uniform: keep them in scalar registers
+    auto uniform = [](double v) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(__double_as_longlong(v) & 0xffffffffll));
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)__double_as_longlong(v) >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    adv_mean = uniform(adv_mean);
+    adv_rstd = uniform(adv_rstd);
+    // head register r of this lane holds output lk + 4 r
+    float inv_std[2] = {0.f, 0.f};
     float sum_logstd = 0.f;
     if (!is_value && gaussian) {
         for (int k = 0; k < g.A; k++) sum_logstd += g.params[g.logstd_off + k];
+        sum_logstd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sum_logstd)));
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int k = 4 * lk + r;
+        for (int r = 0; r < 2; r++) {
+            const int k = lk + 4 * r;
             if (k < g.A) inv_std[r] = expf(-g.params[g.logstd_off + k]);
         }
     }
 
     // ---- gradient accumulators (registers, whole launch) ------------------------------------
     f32x4 dW1[2][HB], dW2[HB][HB], dWh[HB];
-    float db2[HB], dbh = 0.f, dls[4] = {0.f, 0.f, 0.f, 0.f};
+    float db2[HB], dbh = 0.f;
 #pragma unroll
     for (int a = 0; a < HB; a++) {
         db2[a] = 0.f;
@@ -171,103 +222,169 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
             for (int b = 0; b < HB; b++) dW2[a][b][r] = 0.f;
         }
     }
-    double s_pg = 0, s_vf = 0, s_ent = 0, s_kl = 0, s_cf = 0;
+    // per-lane loss sums stay short (one term per tile): float here, double from the wave sum on
+    float s_pg = 0.f, s_vf = 0.f, s_ent = 0.f, s_kl = 0.f, s_cf = 0.f;
 
     const int64_t ntiles = (g.B + 15) >> 4;
     const int64_t wave_global = (int64_t)wg_in_trunk * kWaves + wave;
     const int64_t wave_stride = (int64_t)nwg_trunk * kWaves;
-    const float one0 = lk == 0 ? 1.f : 0.f;
-    const int kq1 = (D + 4) >> 2;              // k-steps over the D inputs + the ones feature
-    const bool wide_in = D + 1 > 16;           // second 16-row block of dW1 in use
+
+    const rsrc_t r_obs = make_rsrc(g.obs, g.n * D * 4);
+    const rsrc_t r_act = make_rsrc(g.actions, gaussian ? g.n * g.A * 4 : g.n * 4);
+    const rsrc_t r_ret = make_rsrc(g.returns, g.n * g.R * 4), r_val = make_rsrc(g.values, g.n * g.R * 4);
+    const rsrc_t r_nlp = make_rsrc(g.neglogpacs, g.n * 4), r_adv = make_rsrc(g.advs, g.n * (g.adv_f64 ? 8 : 4));
+    const rsrc_t r_idx = make_rsrc(g.idx, g.idx ? g.B * 4 : 0);
+
+    // rollout row of this lane's sample in a tile (row 0 stands in for samples past the end: the
+    // index load past the list's end returns 0); sample numbers are int32, so rows are too
+    auto tile_row = [&](int64_t tile) -> int {
+        const int64_t i = tile * 16 + li;
+        int smp;
+        if (g.idx) smp = buf_i32(r_idx, (unsigned)(i < g.B ? i : g.B) * 4u);
+        else smp = i < g.B ? (int)i : 0;
+        if (g.T == 0) return smp;
+        const int env = smp / g.T;
+        return (smp - env * g.T) * g.E + env;
+    };
+    // this lane's share of its sample's observation row: features lk + 4 u (reads past the row's
+    // end bring the next row's values or 0, and are parked in the spare row below)
+    float xr[KQ];
+    auto load_obs = [&](int row) {
+        const unsigned base = (unsigned)row * (unsigned)(D * 4) + (unsigned)(lk * 4);
+#pragma unroll
+        for (int u = 0; u < KQ; u++) xr[u] = buf_f32(r_obs, base + 16u * u);
+    };
+
+    int row = tile_row(wave_global), row_next = tile_row(wave_global + wave_stride);
+    load_obs(row);
 
     for (int64_t tile = wave_global; tile < ntiles; tile += wave_stride) {
-        const int64_t i = tile * 16 + li;
-        const bool live = i < g.B;
-        const int64_t smp = live ? (g.idx ? (int64_t)g.idx[i] : i) : 0;
-        const int64_t row = tm_offset(smp, g.T, g.E);
+        const bool live = tile * 16 + li < g.B;
 
-        // ---- gather the 16 observation rows into the x tile (+ ones feature at column D) ----
-        for (int e = lane; e < 16 * D; e += 64) {
-            const int s = e / D, c = e - s * D;
-            const int64_t srow = __shfl(row, s, 64);
-            xs[s * LDX + c] = g.obs[srow * D + c];
+        // ---- x tile: feature row lk + 4 u, sample li (swz of that row = u & 2) --------------------------
+#pragma unroll
+        for (int u = 0; u < KQ; u++) {
+            const int pos = (lk + 4 * u) * 16 + ((u & 2) ? c1 : c0);
+            xa[lk + 4 * u < D ? pos : SPARE + lane] = xr[u];
         }
-        if (lk == 0) xs[li * LDX + D] = 1.f;
+
+        // ---- this tile's loss inputs, then the next tile's observations and the index after that --------
+        float adv = 0.f, oldnlp = 0.f, act[2] = {0.f, 0.f}, ret[2] = {0.f, 0.f}, oldv[2] = {0.f, 0.f};
+        int act_i = 0;
+        if (!is_value) {
+            double a;
+            if (g.adv_f64) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(r_adv, (int)((unsigned)row * 8u), 0, 0);
+                a = __longlong_as_double((long long)(((unsigned long long)v[1] << 32) | v[0]));
+            } else {
+                a = (double)buf_f32(r_adv, (unsigned)row * 4u);
+            }
+            adv = (float)((a - adv_mean) * adv_rstd);
+            oldnlp = buf_f32(r_nlp, (unsigned)row * 4u);
+            if (gaussian) {      // outputs lk and lk + 4 (ac_dim <= 8)
+                const unsigned base = (unsigned)row * (unsigned)(g.A * 4) + (unsigned)(lk * 4);
+                act[0] = buf_f32(r_act, base);
+                act[1] = buf_f32(r_act, base + 16u);
+            } else {
+                act_i = buf_i32(r_act, (unsigned)row * 4u);
+            }
+        } else {                 // value channels lk and lk + 4 (nvalue <= 8)
+            const unsigned base = (unsigned)row * (unsigned)(g.R * 4) + (unsigned)(lk * 4);
+            ret[0] = buf_f32(r_ret, base);
+            ret[1] = buf_f32(r_ret, base + 16u);
+            oldv[0] = buf_f32(r_val, base);
+            oldv[1] = buf_f32(r_val, base + 16u);
+        }
+        load_obs(row_next);
+        const int row_after = tile_row(tile + 2 * wave_stride);
         __builtin_amdgcn_wave_barrier();
 
-        // ---- forward ---------------------------------------------------------------------
+        // ---- layer 1: h1 = tanh(W1^T [x; 1]) ----------------------------------------------------
         f32x4 h1[HB], h2[HB], out;
 #pragma unroll
         for (int mb = 0; mb < HB; mb++)
 #pragma unroll
             for (int r = 0; r < 4; r++) h1[mb][r] = 0.f;
-        for (int q = 0; q < kq1; q++) {
-            const float b = xs[li * LDX + 4 * q + lk];
+        {
+            f32x4 w[2];
+            float b[2];
+            w[0] = LDS4(W1P + lk * 64 + li * 4);
+            b[0] = xa[lk * 16 + c0];
 #pragma unroll
-            for (int mb = 0; mb < HB; mb++) h1[mb] = MFMA16(w1s[(4 * q + lk) * LDW1 + 16 * mb + li], b, h1[mb]);
+            for (int q = 0; q < KQ; q++) {
+                if (q + 1 < KQ) {       // operands of the next k-step are in flight while this one multiplies
+                    w[(q + 1) & 1] = LDS4(W1P + (4 * (q + 1) + lk) * 64 + li * 4);
+                    b[(q + 1) & 1] = xa[(4 * (q + 1) + lk) * 16 + (((q + 1) & 2) ? c1 : c0)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mb = 0; mb < HB; mb++) h1[mb] = MFMA16(w[q & 1][mb], b[q & 1], h1[mb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int mb = 0; mb < HB; mb++)
 #pragma unroll
             for (int r = 0; r < 4; r++) h1[mb][r] = fast_tanh16(h1[mb][r]);
-
-#pragma unroll
-        for (int m = 0; m < HB; m++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) h2[m][r] = 0.f;
 #pragma unroll
         for (int mb = 0; mb < HB; mb++)
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+            for (int r = 0; r < 4; r++) ta[dpos + (16 * mb + r) * 16] = h1[mb][r];
+
+        // ---- layer 2: h2 = tanh(W2^T h1 + b2); the bias seeds the accumulator ------------------------
+        {
+            f32x4 w[2][HB];
 #pragma unroll
-                for (int m = 0; m < HB; m++)
-                    h2[m] = MFMA16(w2s[(16 * mb + 4 * lk + r) * LDW2 + 16 * m + li], h1[mb][r], h2[m]);
+            for (int m = 0; m < HB; m++) {
+                h2[m] = LDS4(B2 + 16 * m + 4 * lk);
+                w[0][m] = LDS4(W2P + wpos + 64 * m);
+            }
 #pragma unroll
-        for (int m = 0; m < HB; m++) h2[m] = MFMA16(b2s[16 * m + li] * one0, one0, h2[m]);        // + bias
+            for (int mb = 0; mb < HB; mb++) {
+                if (mb + 1 < HB) {
+#pragma unroll
+                    for (int m = 0; m < HB; m++) w[(mb + 1) & 1][m] = LDS4(W2P + wpos + 1024 * (mb + 1) + 64 * m);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int m = 0; m < HB; m++) h2[m] = MFMA16(w[mb & 1][m][r], h1[mb][r], h2[m]);
+            }
+        }
 #pragma unroll
         for (int m = 0; m < HB; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++) h2[m][r] = fast_tanh16(h2[m][r]);
+#pragma unroll
+        for (int m = 0; m < HB; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) tb[dpos + (16 * m + r) * 16] = h2[m][r];
 
+        // ---- head: register r of lane quarter lk = output lk + 4 r ----------------------------------
+        {
+            f32x4 w[HB];
+            out = LDS4(BHP + 4 * lk);
 #pragma unroll
-        for (int r = 0; r < 4; r++) out[r] = 0.f;
+            for (int mb = 0; mb < HB; mb++) w[mb] = LDS4(WHP + (lk * 16 + li) * 4 + 256 * mb);
 #pragma unroll
-        for (int mb = 0; mb < HB; mb++)
+            for (int mb = 0; mb < HB; mb++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) out = MFMA16(whs[(16 * mb + 4 * lk + r) * LDWH + li], h2[mb][r], out);
-        out = MFMA16(bhs[li] * one0, one0, out);
+                for (int r = 0; r < 4; r++) out = MFMA16(w[mb][r], h2[mb][r], out);
+        }
 
-        // transposed copies of the activations for the weight-gradient products
-#pragma unroll
-        for (int mb = 0; mb < HB; mb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                ta[(16 * mb + 4 * lk + r) * LDT + li] = h1[mb][r];
-                tb[(16 * mb + 4 * lk + r) * LDT + li] = h2[mb][r];
-            }
-
-        // ---- loss and d(loss)/d(out): output row 4 lk + r of sample li -------------------------
+        // ---- loss and d(loss)/d(out) ------------------------------------------------------------------
         f32x4 dout;
 #pragma unroll
         for (int r = 0; r < 4; r++) dout[r] = 0.f;
         if (!is_value) {
-            float adv = 0.f, oldnlp = 0.f;
-            if (live) {
-                const double a = g.adv_f64 ? ((const double *)g.advs)[row] : (double)((const float *)g.advs)[row];
-                adv = (float)((a - adv_mean) * adv_rstd);
-                oldnlp = g.neglogpacs[row];
-            }
             float nlp, entropy_row;
-            float zq[4] = {0.f, 0.f, 0.f, 0.f}, pr[4] = {0.f, 0.f, 0.f, 0.f}, lp[4] = {0.f, 0.f, 0.f, 0.f};
-            int act_i = 0;
+            float zq[2] = {0.f, 0.f}, pr[4] = {0.f, 0.f, 0.f, 0.f}, lp[4] = {0.f, 0.f, 0.f, 0.f};
             if (gaussian) {
-                const float *act = (const float *)g.actions + row * g.A;
                 float ss = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int k = 4 * lk + r;
-                    if (k < g.A) {
-                        zq[r] = (act[k] - out[r]) * inv_std[r];
+                for (int r = 0; r < 2; r++) {
+                    if (lk + 4 * r < g.A) {
+                        zq[r] = (act[r] - out[r]) * inv_std[r];
                         ss += zq[r] * zq[r];
                     }
                 }
@@ -276,17 +393,16 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
                 nlp = 0.5f * ss + 0.91893853320467274178f * (float)g.A + sum_logstd;
                 entropy_row = sum_logstd + (0.91893853320467274178f + 0.5f) * (float)g.A;
             } else {
-                act_i = ((const int32_t *)g.actions)[row];
                 float mx = -3.0e38f;
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    if (4 * lk + r < g.A) mx = fmaxf(mx, out[r]);
+                    if (lk + 4 * r < g.A) mx = fmaxf(mx, out[r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 float z0 = 0.f, la = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int k = 4 * lk + r;
+                    const int k = lk + 4 * r;
                     pr[r] = k < g.A ? expf(out[r] - mx) : 0.f;
                     z0 += pr[r];
                     if (k == act_i) la = out[r] - mx;
@@ -300,7 +416,7 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
                 float Hs = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int k = 4 * lk + r;
+                    const int k = lk + 4 * r;
                     pr[r] = pr[r] / z0;
                     lp[r] = k < g.A ? (out[r] - mx) - logz : 0.f;      // log p_k
                     Hs -= pr[r] * lp[r];
@@ -314,142 +430,184 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
             const float pg2 = -adv * fminf(fmaxf(ratio, 1.0f - g.cliprange), 1.0f + g.cliprange);
             const float dnlp = (live && pg1 >= pg2) ? adv * ratio * g.inv_count : 0.f;
             if (live && lk == 0) {
-                s_pg += (double)fmaxf(pg1, pg2);
+                s_pg += fmaxf(pg1, pg2);
                 const float d = nlp - oldnlp;
-                s_kl += 0.5 * (double)(d * d);
-                s_cf += (fabsf(ratio - 1.0f) > g.cliprange) ? 1.0 : 0.0;
-                s_ent += (double)entropy_row;
+                s_kl += 0.5f * (d * d);
+                s_cf += (fabsf(ratio - 1.0f) > g.cliprange) ? 1.f : 0.f;
+                s_ent += entropy_row;
             }
             if (gaussian) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int k = 4 * lk + r;
-                    if (k < g.A) {
-                        dout[r] = dnlp * (-zq[r] * inv_std[r]);
-                        if (live) dls[r] += dnlp * (1.f - zq[r] * zq[r]) - g.ent_coef * g.inv_count;
-                    }
+                for (int r = 0; r < 2; r++) {
+                    if (lk + 4 * r < g.A) dout[r] = dnlp * (-zq[r] * inv_std[r]);
                 }
+                // d(loss)/d(logstd_o) of this sample rides in the unused head rows 8 + o (ac_dim <= 8): the
+                // bias-gradient row sums below then add it up over samples; the matching weight rows are zero
+                const float dent = live ? g.ent_coef * g.inv_count : 0.f;
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+                    if (lk + 4 * r < g.A) dout[r + 2] = dnlp * (1.f - zq[r] * zq[r]) - dent;
             } else {
                 const float ec = live ? g.ent_coef * g.inv_count : 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int k = 4 * lk + r;
+                    const int k = lk + 4 * r;
                     if (k < g.A) dout[r] = dnlp * (pr[r] - (k == act_i ? 1.f : 0.f)) + ec * pr[r] * (lp[r] + entropy_row);
                 }
             }
         } else {
-            const float sc = g.inv_count / (float)g.R;
+            const float sc = g.inv_count / (float)g.R, rR = 1.f / (float)g.R;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int k = 4 * lk + r;
-                if (k < g.R && live) {
-                    const float v = out[r], ret = g.returns[row * g.R + k];
-                    const float e1 = v - ret;
+            for (int r = 0; r < 2; r++) {
+                if (lk + 4 * r < g.R && live) {
+                    const float v = out[r];
+                    const float e1 = v - ret[r];
                     if (g.upstream) {
-                        const float ov = g.values[row * g.R + k];
-                        const float dv = v - ov;
-                        const float vc = ov + fminf(fmaxf(dv, -g.cliprange), g.cliprange);
-                        const float e2 = vc - ret;
+                        const float dv = v - oldv[r];
+                        const float vc = oldv[r] + fminf(fmaxf(dv, -g.cliprange), g.cliprange);
+                        const float e2 = vc - ret[r];
                         const float l1 = e1 * e1, l2 = e2 * e2;
-                        s_vf += 0.5 * (double)fmaxf(l1, l2) / (double)g.R;
+                        s_vf += 0.5f * fmaxf(l1, l2) * rR;
                         const float gg = (l1 >= l2) ? e1 : ((dv >= -g.cliprange && dv <= g.cliprange) ? e2 : 0.f);
                         dout[r] = g.vf_coef * sc * gg;
                     } else {
-                        s_vf += (double)(e1 * e1) / (double)g.R;
+                        s_vf += (e1 * e1) * rR;
                         dout[r] = 2.f * e1 * sc;
                     }
                 }
             }
         }
+        // output lk + 4 r is row lk + 4 r of the head tile (swz of that row = r & 2)
 #pragma unroll
-        for (int r = 0; r < 4; r++) tc[(4 * lk + r) * LDT + li] = dout[r];
+        for (int r = 0; r < 4; r++) tc[(lk + 4 * r) * 16 + ((r & 2) ? c1 : c0)] = dout[r];
         __builtin_amdgcn_wave_barrier();
 
         // ---- head: weight gradient (h2^T dout; bias gradient = row sums of dout^T) -------------------
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float b = tc[li * LDT + 4 * q + lk];
-            dbh += b;
-#pragma unroll
-            for (int mi = 0; mi < HB; mi++) dWh[mi] = MFMA16(tb[(16 * mi + li) * LDT + 4 * q + lk], b, dWh[mi]);
-        }
-        // ---- head: input gradient, through tanh' ----------------------------------------------------
         f32x4 dz2[HB];
+        {
+            f32x4 a[HB], wt[HB];
+            const f32x4 b = LDS4(WEIGHTS + wave * WAVE + TC + rpos);
 #pragma unroll
-        for (int m = 0; m < HB; m++)
+            for (int mi = 0; mi < HB; mi++) a[mi] = LDS4(WEIGHTS + wave * WAVE + TB + rpos + 256 * mi);
 #pragma unroll
-            for (int r = 0; r < 4; r++) dz2[m][r] = 0.f;
+            for (int m = 0; m < HB; m++) wt[m] = LDS4(WHTP + wpos + 64 * m);
+            dbh += (b[0] + b[1]) + (b[2] + b[3]);
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+            for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int m = 0; m < HB; m++) dz2[m] = MFMA16(whts[(4 * lk + r) * LDWHT + 16 * m + li], dout[r], dz2[m]);
+                for (int mi = 0; mi < HB; mi++) dWh[mi] = MFMA16(a[mi][q], b[q], dWh[mi]);
+            // ---- head: input gradient over the registers that hold real outputs ----------------------
 #pragma unroll
-        for (int m = 0; m < HB; m++)
+            for (int m = 0; m < HB; m++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) dz2[m][r] *= 1.f - h2[m][r] * h2[m][r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int m = 0; m < HB; m++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) tb[(16 * m + 4 * lk + r) * LDT + li] = dz2[m][r];
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- layer 2: weight gradient (h1^T dz2), bias gradient from the same operand reads ---------
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            float a[HB], b[HB];
-#pragma unroll
-            for (int mi = 0; mi < HB; mi++) a[mi] = ta[(16 * mi + li) * LDT + 4 * q + lk];
-#pragma unroll
-            for (int mj = 0; mj < HB; mj++) {
-                b[mj] = tb[(16 * mj + li) * LDT + 4 * q + lk];
-                db2[mj] += b[mj];
-            }
-#pragma unroll
-            for (int mi = 0; mi < HB; mi++)
-#pragma unroll
-                for (int mj = 0; mj < HB; mj++) dW2[mi][mj] = MFMA16(a[mi], b[mj], dW2[mi][mj]);
-        }
-        // ---- layer 2: input gradient, through tanh' ----------------------------------------------------
-        f32x4 dz1[HB];
-#pragma unroll
-        for (int mb = 0; mb < HB; mb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) dz1[mb][r] = 0.f;
-#pragma unroll
-        for (int m = 0; m < HB; m++)
+                for (int r = 0; r < 4; r++) dz2[m][r] = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; r++)
+                if (r < nr) {
 #pragma unroll
-                for (int mb = 0; mb < HB; mb++)
-                    dz1[mb] = MFMA16(w2ts[(16 * m + 4 * lk + r) * LDW2 + 16 * mb + li], dz2[m][r], dz1[mb]);
+                    for (int m = 0; m < HB; m++) dz2[m] = MFMA16(wt[m][r], dout[r], dz2[m]);
+                }
+        }
+        // tanh' from the activations still sitting in the tile, then the tile takes the gradient
+#pragma unroll
+        for (int m = 0; m < HB; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float t = tb[dpos + (16 * m + r) * 16];
+                dz2[m][r] *= 1.f - t * t;
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < HB; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) tb[dpos + (16 * m + r) * 16] = dz2[m][r];
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- layer 2: input gradient first (dz2 is still in registers) ------------------------------------
+        f32x4 dz1[HB];
+        {
+            f32x4 wt[2][HB];
+#pragma unroll
+            for (int mb = 0; mb < HB; mb++) wt[0][mb] = LDS4(W2TP + wpos + 64 * mb);
+#pragma unroll
+            for (int mb = 0; mb < HB; mb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) dz1[mb][r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < HB; m++) {
+                if (m + 1 < HB) {
+#pragma unroll
+                    for (int mb = 0; mb < HB; mb++) wt[(m + 1) & 1][mb] = LDS4(W2TP + wpos + 1024 * (m + 1) + 64 * mb);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int mb = 0; mb < HB; mb++) dz1[mb] = MFMA16(wt[m & 1][mb][r], dz2[m][r], dz1[mb]);
+            }
+        }
 #pragma unroll
         for (int mb = 0; mb < HB; mb++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) dz1[mb][r] *= 1.f - h1[mb][r] * h1[mb][r];
+            for (int r = 0; r < 4; r++) {
+                const float t = ta[dpos + (16 * mb + r) * 16];
+                dz1[mb][r] *= 1.f - t * t;
+            }
+        // ---- layer 2: weight gradient (h1^T dz2 from the tiles), bias gradient from the same operand reads ---
+        {
+            f32x4 a[HB], b[HB];
+#pragma unroll
+            for (int m = 0; m < HB; m++) {
+                a[m] = LDS4(WEIGHTS + wave * WAVE + TA + rpos + 256 * m);
+                b[m] = LDS4(WEIGHTS + wave * WAVE + TB + rpos + 256 * m);
+            }
+#pragma unroll
+            for (int mj = 0; mj < HB; mj++) db2[mj] += (b[mj][0] + b[mj][1]) + (b[mj][2] + b[mj][3]);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int mi = 0; mi < HB; mi++)
+#pragma unroll
+                    for (int mj = 0; mj < HB; mj++) dW2[mi][mj] = MFMA16(a[mi][q], b[mj][q], dW2[mi][mj]);
+        }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int mb = 0; mb < HB; mb++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) ta[(16 * mb + 4 * lk + r) * LDT + li] = dz1[mb][r];
+            for (int r = 0; r < 4; r++) ta[dpos + (16 * mb + r) * 16] = dz1[mb][r];
         __builtin_amdgcn_wave_barrier();
 
         // ---- layer 1: weight (+ bias, through the ones feature) gradient --------------------------------
+        {
+            f32x4 b[HB];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            float b[HB];
+            for (int mj = 0; mj < HB; mj++) b[mj] = LDS4(WEIGHTS + wave * WAVE + TA + rpos + 256 * mj);
+            const f32x4 a0 = LDS4(WEIGHTS + wave * WAVE + XA + rpos);
 #pragma unroll
-            for (int mj = 0; mj < HB; mj++) b[mj] = ta[(16 * mj + li) * LDT + 4 * q + lk];
-            const float a0 = xs[(4 * q + lk) * LDX + li];
+            for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int mj = 0; mj < HB; mj++) dW1[0][mj] = MFMA16(a0, b[mj], dW1[0][mj]);
-            if (wide_in) {
-                const float a1 = xs[(4 * q + lk) * LDX + 16 + li];
+                for (int mj = 0; mj < HB; mj++) dW1[0][mj] = MFMA16(a0[q], b[mj][q], dW1[0][mj]);
+            if (WIDE) {
+                const f32x4 a1 = LDS4(WEIGHTS + wave * WAVE + XA + rpos + 256);
 #pragma unroll
-                for (int mj = 0; mj < HB; mj++) dW1[1][mj] = MFMA16(a1, b[mj], dW1[1][mj]);
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int mj = 0; mj < HB; mj++) dW1[1][mj] = MFMA16(a1[q], b[mj][q], dW1[1][mj]);
             }
         }
         __builtin_amdgcn_wave_barrier();
+        row = row_next;
+        row_next = row_after;
+    }
+
+    // ---- loss partial row of this workgroup: wave sums, then eight values per output in fixed order ----
+    {
+        double vals[kLossVals];
+        vals[0] = (double)s_pg; vals[1] = (double)s_vf; vals[2] = (double)s_ent; vals[3] = (double)s_kl; vals[4] = (double)s_cf;
+#pragma unroll
+        for (int k = 0; k < kLossVals; k++) {
+            const double v = wave_sum(vals[k]);
+            if (lane == 0) red[wave * kLossVals + k] = v;
+        }
     }
 
     // ---- cross-wave reduction of the gradient images (two rounds of four), one slab per workgroup ------
@@ -493,21 +651,13 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
         const float *p = lds + e;
         slab[e] = (p[0] + p[SLAB]) + (p[2 * SLAB] + p[3 * SLAB]);
     }
-
-    // ---- loss partial row of this workgroup ---------------------------------------------------------
-    double *lpr = g.loss_partial + (int64_t)blockIdx.x * kLossStride;
-    double v;
-    v = block_sum(s_pg, red);  if (tid == 0) lpr[0] = v;
-    v = block_sum(s_vf, red);  if (tid == 0) lpr[1] = v;
-    v = block_sum(s_ent, red); if (tid == 0) lpr[2] = v;
-    v = block_sum(s_kl, red);  if (tid == 0) lpr[3] = v;
-    v = block_sum(s_cf, red);  if (tid == 0) lpr[4] = v;
-    for (int k = 0; k < 16; k++) {
-        // dlogstd[k]: register k & 3 of lane quarter k >> 2
-        const double mine = (!is_value && gaussian && lk == (k >> 2)) ? (double)dls[k & 3] : 0.0;
-        v = block_sum(mine, red);
-        if (tid == 0) lpr[8 + k] = v;
+    if (tid < kLossVals) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) v += red[w * kLossVals + tid];
+        g.loss_partial[(int64_t)blockIdx.x * kLossStride + tid] = v;
     }
+#undef LDS4
 }
 
 bool mlp_fused16_supported(const ppo2hip_policy_desc &d) {
@@ -515,7 +665,13 @@ bool mlp_fused16_supported(const ppo2hip_policy_desc &d) {
     if (d.hidden1 != 64 || d.hidden2 != 64) return false;
     if (d.ob_dim < 1 || d.ob_dim > 31) return false;
     if (d.nvalue > 8) return false;
-    return d.ac_dim <= 16;
+    return d.ac_dim <= (d.dist == PPO2HIP_DIST_GAUSSIAN ? 8 : 16);   // Gaussian: rows 8.. carry the logstd gradient
+}
+
+bool mlp_fused16_fits(const ppo2hip_policy_desc &d, const ppo2hip_rollout &ro, int64_t B) {
+    const int64_t widest = std::max<int64_t>(std::max<int64_t>(d.ob_dim, d.ac_dim), std::max<int64_t>(d.nvalue, 2));
+    const int64_t limit = (int64_t(1) << 32) - 4096;
+    return ro.n > 0 && ro.n * widest * 4 < limit && B * 4 < limit;
 }
 
 int mlp_fused16_grid() { return 256; }   // one 512-thread workgroup per CU (LDS-limited), 128 per trunk
@@ -539,18 +695,21 @@ int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, 
     double *lpart = (double *)((char *)ws + align_up((size_t)grid * SLAB * sizeof(float), 256));
     Fused16Args g;
     g.obs = (const float *)ro.obs; g.actions = ro.actions; g.returns = ro.returns; g.values = ro.values;
-    g.neglogpacs = ro.neglogpacs; g.advs = ro.advs; g.adv_f64 = ro.adv_f64; g.T = ro.T; g.E = ro.E;
+    g.neglogpacs = ro.neglogpacs; g.advs = ro.advs; g.adv_f64 = ro.adv_f64; g.T = ro.T; g.E = ro.E; g.n = ro.n;
     g.idx = idx; g.B = B; g.stats = stats; g.params = params;
     g.a_w1 = fo.a_w1; g.a_w2 = fo.a_w2; g.a_wh = fo.a_wh; g.v_w1 = fo.v_w1; g.v_w2 = fo.v_w2; g.v_wh = fo.v_wh;
     g.logstd_off = fo.logstd; g.D = d.ob_dim; g.A = d.ac_dim; g.R = d.nvalue; g.dist = d.dist;
     g.upstream = lc.upstream; g.cliprange = cliprange; g.ent_coef = lc.ent_coef;
     g.vf_coef = lc.upstream ? lc.vf_coef : 1.0f; g.inv_count = (float)inv_count;
     g.slabs = slabs; g.loss_partial = lpart;
-    hipLaunchKernelGGL(mlp_fused16_kernel, dim3(grid), dim3(kThreads), 0, s, g);
+    if (d.ob_dim <= 7) hipLaunchKernelGGL((mlp_fused16_kernel<2, false>), dim3(grid), dim3(kThreads), 0, s, g);
+    else if (d.ob_dim <= 15) hipLaunchKernelGGL((mlp_fused16_kernel<4, false>), dim3(grid), dim3(kThreads), 0, s, g);
+    else if (d.ob_dim <= 19) hipLaunchKernelGGL((mlp_fused16_kernel<5, true>), dim3(grid), dim3(kThreads), 0, s, g);
+    else hipLaunchKernelGGL((mlp_fused16_kernel<8, true>), dim3(grid), dim3(kThreads), 0, s, g);
     int rc = check_launch("mlp_fused16_kernel");
     if (rc) return rc;
     FusedImage im;
-    im.slab_elems = SLAB; im.s_w1 = S_W1; im.s_w2 = S_W2; im.s_wh = S_WH; im.s_bh = S_BH; im.head_cols = 16;
+    im.slab_elems = SLAB; im.s_w1 = S_W1; im.s_w2 = S_W2; im.s_wh = S_WH; im.s_bh = S_BH; im.head_cols = 16; im.s_logstd = S_BH + 8;
     return fused_finalize(im, slabs, grid / 2, lpart, grid, d, fo, inv_count, grads, losses, s);
 }
 

@@ -194,9 +194,9 @@ static int mlp_trunk_backward(const float *X, int D, const float *H1, int h1, co
 
 // PPO2HIP_MLP_PATH = layered | fused32 | fused16 pins one of the routes for shapes that several
 // cover (the tests check them against each other); default: the fastest that supports the shape.
-static int mlp_path_choice(const ppo2hip_policy_desc &d) {
+static int mlp_path_choice(const ppo2hip_policy_desc &d, const ppo2hip_rollout &ro, int64_t B) {
     const char *e = getenv("PPO2HIP_MLP_PATH");
-    const bool f16 = mlp_fused16_supported(d), f32 = mlp_fused_supported(d);
+    const bool f16 = mlp_fused16_supported(d) && mlp_fused16_fits(d, ro, B), f32 = mlp_fused_supported(d);
     if (e && std::strcmp(e, "layered") == 0) return 0;
     if (e && std::strcmp(e, "fused32") == 0 && f32) return 32;
     if (e && std::strcmp(e, "fused16") == 0 && f16) return 16;
@@ -215,7 +215,7 @@ static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
     }
     const int D = d.ob_dim, h1 = d.hidden1, h2 = d.hidden2, A = d.ac_dim, R = d.nvalue;
     const bool gauss = d.dist == PPO2HIP_DIST_GAUSSIAN;
-    const int path = mlp_path_choice(d);
+    const int path = mlp_path_choice(d, ro, B);
     if (path) {
         FusedOffsets fo{L.off("pi_fc1/w"), L.off("pi_fc2/w"), L.off("pi/w"), L.off("vf_fc1/w"), L.off("vf_fc2/w"),
                         L.off("vf/w"), gauss ? L.off("logstd") : 0};
@@ -587,6 +587,10 @@ extern "C" int ppo2hip_ppo_grad(const ppo2hip_policy_desc *desc, const ppo2hip_l
     PPO2HIP_REQUIRE(rollout->obs && rollout->actions && rollout->returns && rollout->values &&
                     rollout->neglogpacs && rollout->advs, "ppo_grad: rollout has null arrays");
     PPO2HIP_REQUIRE(rollout->T == 0 || (rollout->T > 0 && rollout->E > 0), "ppo_grad: bad rollout shape");
+    PPO2HIP_REQUIRE(rollout->n > 0 && (rollout->T == 0 || rollout->n == (int64_t)rollout->T * rollout->E),
+                    "ppo_grad: rollout.n=%lld does not match T=%d E=%d", (long long)rollout->n, rollout->T, rollout->E);
+    PPO2HIP_REQUIRE(idx || B <= rollout->n, "ppo_grad: B=%lld rows asked of a %lld-row rollout", (long long)B,
+                    (long long)rollout->n);
     Layout L;
     int rc = build_layout(*desc, L);
     if (rc) return rc;

@@ -355,7 +355,7 @@ class RolloutRef:
                               neglogpacs.data_ptr(), advs.data_ptr(),
                               masks.data_ptr() if masks is not None else None,
                               states.data_ptr() if states is not None else None,
-                              int(advs.dtype == torch.float64), T, E)
+                              int(advs.dtype == torch.float64), T, E, 0, n)
 
 
 def ppo_grad(spec, loss_desc, params, rollout, idx, B, stats, cliprange, inv_count, grads, losses, workspace,

@@ -177,7 +177,8 @@ int ppo2hip_param_layout(const ppo2hip_policy_desc *desc, int max_vars, char (*n
  * s = idx[i] (or s = i when idx is NULL), i.e. env = s / T, t = s % T — the indexing
  * that `arr[mbinds]` applies to the sf01-flattened arrays at baselines/ppo2/ppo2.py:117
  * and :134-136 — read in place at [t, env].  T = 0 means the arrays are already
- * flat [N, ...] and s indexes them directly (what Model.train receives, :65). */
+ * flat [N, ...] and s indexes them directly (what Model.train receives, :65).
+ * n = rows held by every array (T * E when T > 0): the range idx values must stay in. */
 typedef struct ppo2hip_rollout {
     const void *obs;         /* float32 [.., ob_dim] or uint8 [.., H, W, C] */
     const void *actions;     /* float32 [.., ac_dim] (Gaussian) or int32 [..] (Categorical) */
@@ -189,6 +190,7 @@ typedef struct ppo2hip_rollout {
     const float *states;     /* [E, 2*nlstm] initial LSTM states of the rollout; recurrent only */
     int32_t adv_f64;
     int32_t T, E;
+    int64_t n;
 } ppo2hip_rollout;
 
 size_t ppo2hip_forward_workspace_bytes(const ppo2hip_policy_desc *desc, int64_t B);
