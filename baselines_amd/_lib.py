@@ -67,6 +67,8 @@ _SIGS = {
     "ppo2hip_perm_create": (c_void_p, [c_void_p, c_int64, c_int]),
     "ppo2hip_perm_destroy": (None, [c_void_p]),
     "ppo2hip_perm_begin": (c_int, [c_void_p, c_int, _P]),
+    "ppo2hip_perm_begin_relative": (c_int, [c_void_p, c_int, _P]),
+    "ppo2hip_compose_i32": (c_int, [_P, _P, _P, c_int64, _P]),
     "ppo2hip_perm_wait": (c_int, [c_void_p, c_int]),
     "ppo2hip_perm_wait_all": (c_int, [c_void_p]),
     "ppo2hip_param_count": (c_int64, [POINTER(PolicyDesc)]),
@@ -78,6 +80,9 @@ _SIGS = {
     "ppo2hip_ppo_grad": (c_int, [POINTER(PolicyDesc), POINTER(LossDesc), _P, POINTER(Rollout), _P, c_int64, _P,
                                  c_int32, _P, c_float, c_double, _P, _P, _P, c_size_t, _P]),
     "ppo2hip_adam_scratch_bytes": (c_size_t, [c_int64]),
+    "ppo2hip_ppo_epoch": (c_int, [POINTER(PolicyDesc), POINTER(LossDesc), _P, _P, _P, _P, POINTER(Rollout), _P, c_int64,
+                                  c_int64, _P, c_float, c_double, c_int64, c_double, c_double, c_double, c_double, _P,
+                                  _P, c_size_t, _P, _P]),
     "ppo2hip_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_double, c_int64, c_double, c_double, c_double,
                                   c_double, c_double, _P, _P]),
     "ppo2hip_gemm_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

@@ -114,3 +114,28 @@ int gather_states(const float *states, const int32_t *envs, int nenv_mb, int wid
 }
 
 }  // namespace ppo2hip
+
+// ---------------------------------------------------------------------------------------
+// Composition of permutations: the running minibatch order after one more epoch's shuffle
+// (inds_e = inds_{e-1}[sigma_e], the in-place np.random.shuffle of baselines/ppo2/ppo2.py:113
+// restated as a gather).
+// ---------------------------------------------------------------------------------------
+namespace ppo2hip {
+__global__ void compose_kernel(const int32_t *__restrict__ prev, const int32_t *__restrict__ sigma,
+                               int32_t *__restrict__ out, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int32_t s = sigma[k];
+    out[k] = (s >= 0 && s < n) ? prev[s] : 0;
+}
+}  // namespace ppo2hip
+
+extern "C" int ppo2hip_compose_i32(const int32_t *prev, const int32_t *sigma, int32_t *out, int64_t n, void *stream) {
+    using namespace ppo2hip;
+    PPO2HIP_REQUIRE(n >= 0 && n <= 0x7fffffffll, "compose: bad n=%lld", (long long)n);
+    if (n == 0) return PPO2HIP_OK;
+    PPO2HIP_REQUIRE(prev && sigma && out && out != prev && out != sigma, "compose: null or aliased pointer");
+    hipLaunchKernelGGL(compose_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, prev, sigma,
+                       out, n);
+    return check_launch("compose_kernel");
+}

@@ -604,3 +604,29 @@ extern "C" int ppo2hip_ppo_grad(const ppo2hip_policy_desc *desc, const ppo2hip_l
     set_error("ppo_grad: policy kind %d (layer-normalised LSTM) is not built", desc->kind);
     return PPO2HIP_EUNSUPPORTED;
 }
+
+extern "C" int ppo2hip_ppo_epoch(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss, float *params,
+                                 float *grads, float *adam_m, float *adam_v, const ppo2hip_rollout *rollout,
+                                 const int32_t *idx, int64_t N, int64_t nbatch_train, const double *stats,
+                                 float cliprange, double lr, int64_t t_first, double beta1, double beta2,
+                                 double epsilon, double max_grad_norm, float *losses, void *workspace,
+                                 size_t workspace_bytes, void *adam_scratch, void *stream) {
+    PPO2HIP_REQUIRE(desc && idx && adam_m && adam_v && adam_scratch && losses, "ppo_epoch: null pointer");
+    PPO2HIP_REQUIRE(nbatch_train >= 1 && N >= nbatch_train && N % nbatch_train == 0,
+                    "ppo_epoch: N=%lld is not a multiple of nbatch_train=%lld", (long long)N, (long long)nbatch_train);
+    PPO2HIP_REQUIRE(desc->kind == PPO2HIP_POLICY_MLP || desc->kind == PPO2HIP_POLICY_CNN,
+                    "ppo_epoch: feed-forward policies only (recurrent minibatches are env sequences)");
+    const int64_t nmb = N / nbatch_train;
+    const int64_t P = ppo2hip_param_count(desc);
+    if (P < 0) return PPO2HIP_EINVAL;
+    for (int64_t j = 0; j < nmb; j++) {
+        int rc = ppo2hip_ppo_grad(desc, loss, params, rollout, idx + j * nbatch_train, nbatch_train, nullptr, 0,
+                                  stats ? stats + 3 * j : nullptr, cliprange, 1.0 / (double)nbatch_train, grads,
+                                  losses + 8 * j, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        rc = ppo2hip_adam_step(params, grads, adam_m, adam_v, P, lr, t_first + j, beta1, beta2, epsilon, 1.0,
+                               max_grad_norm, adam_scratch, stream);
+        if (rc) return rc;
+    }
+    return PPO2HIP_OK;
+}

@@ -10,9 +10,10 @@
 //           targets j_i, compacted without a data-dependent branch (the accept test only
 //           steers an index increment);
 //   swap  : x[i] <-> x[j_i] with the target cache lines prefetched.
-// ppo2hip_shuffle_* runs both stages inline; the ppo2hip_perm_* pipeline runs them on two
-// worker threads and produces the cumulative shuffles of all epochs of an update ahead of
-// the GPU, so index generation overlaps the kernels of the previous epoch.
+// ppo2hip_shuffle_* runs both stages inline; the ppo2hip_perm_* pipeline runs them on worker
+// threads and produces the cumulative shuffles of all epochs of an update ahead of the GPU,
+// so index generation overlaps the kernels of the previous epoch.
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
@@ -65,20 +66,24 @@ inline uint32_t temper(uint32_t y) {
     return y;
 }
 
-// Buffered view of the stream: tempered outputs of the current 624-word block.
-struct Stream {
+// Buffered view of the stream, one 624-word block of tempered outputs at a time: out[pos ..)
+// are the unread outputs of the current block, refill() moves to the next block.
+struct InlineStream {
     ppo2hip_rng *s;
-    uint32_t out[N];
-    explicit Stream(ppo2hip_rng *r) : s(r) {
-        if (s->pos < N) fill();
+    uint32_t buf[N];
+    const uint32_t *out = buf;
+    int pos;
+    explicit InlineStream(ppo2hip_rng *r) : s(r), pos(r->pos) {
+        if (pos < N) fill();
     }
+    ~InlineStream() { s->pos = pos; }
     void fill() {
-        for (int i = 0; i < N; i++) out[i] = temper(s->mt[i]);
+        for (int i = 0; i < N; i++) buf[i] = temper(s->mt[i]);
     }
     void refill() {
         regenerate(s->mt);
-        s->pos = 0;
         fill();
+        pos = 0;
     }
 };
 
@@ -105,21 +110,45 @@ static const PackLut g_pack;
 // 8 / 2^k of the blocks) the block is compacted with one vector permute; otherwise, and
 // near buffer or mask-range ends, candidates go through the scalar loop, in which the
 // accept test only steers an index increment (no data-dependent branch).
-void draw_targets(Stream &st, int64_t hi, int64_t lo, uint32_t *js) {
-    ppo2hip_rng *s = st.s;
+template <class S>
+void draw_targets(S &st, int64_t hi, int64_t lo, uint32_t *js) {
     int64_t i = hi;
     int64_t w = 0;
     while (i >= lo) {
-        if (s->pos >= N) st.refill();
+        if (st.pos >= N) st.refill();
         uint32_t mask = (uint32_t)i;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
         // positions that share this mask: i down to max(lo, (mask >> 1) + 1)
         const int64_t lim_mask = (int64_t)(mask >> 1) + 1;
         const int64_t stop = lim_mask > lo ? lim_mask : lo;
-        int p = s->pos;
+        int p = st.pos;
 #if defined(__AVX2__)
         if (mask <= 0x7fffffffu) {
             const __m256i vmask = _mm256_set1_epi32((int)mask);
+            // 64 candidates against thresholds fixed on entry: the k-th one's true bound lies in
+            // [i-63, i], so a value <= i-63 is accepted and one > i rejected whatever happens
+            // before it; with no value in between (all but ~64 * 63 / 2^k of the groups) the
+            // eight blocks are classified with no dependence on each other's accept counts.
+            while (p + 64 <= N && i - 63 >= stop) {
+                const __m256i t_lo = _mm256_set1_epi32((int)(i - 63)), t_hi = _mm256_set1_epi32((int)i);
+                __m256i v[8], amb = _mm256_setzero_si256();
+                int acc[8];
+                for (int b = 0; b < 8; b++) {
+                    v[b] = _mm256_and_si256(_mm256_loadu_si256((const __m256i *)(st.out + p + 8 * b)), vmask);
+                    const __m256i gt_lo = _mm256_cmpgt_epi32(v[b], t_lo);
+                    amb = _mm256_or_si256(amb, _mm256_xor_si256(gt_lo, _mm256_cmpgt_epi32(v[b], t_hi)));
+                    acc[b] = (~_mm256_movemask_ps(_mm256_castsi256_ps(gt_lo))) & 0xff;
+                }
+                if (!_mm256_testz_si256(amb, amb)) break;     // decide this stretch block by block
+                const int64_t w0 = w;
+                for (int b = 0; b < 8; b++) {
+                    _mm256_storeu_si256((__m256i *)(js + w),
+                                        _mm256_permutevar8x32_epi32(v[b], _mm256_load_si256((const __m256i *)g_pack.idx[acc[b]])));
+                    w += __builtin_popcount(acc[b]);
+                }
+                i -= w - w0;
+                p += 64;
+            }
             while (p + 8 <= N && i - 7 >= stop) {
                 const __m256i v = _mm256_and_si256(_mm256_loadu_si256((const __m256i *)(st.out + p)), vmask);
                 const __m256i gt_lo = _mm256_cmpgt_epi32(v, _mm256_set1_epi32((int)(i - 7)));   // v > i-7
@@ -146,7 +175,7 @@ void draw_targets(Stream &st, int64_t hi, int64_t lo, uint32_t *js) {
             w += acc;
             i -= acc;
         }
-        s->pos = p;
+        st.pos = p;
     }
 }
 
@@ -174,7 +203,7 @@ int shuffle_impl(ppo2hip_rng *rng, I *x, int64_t n) {
     }
     constexpr int64_t BLK = 4096;
     std::vector<uint32_t> js(BLK + 16);
-    Stream st(rng);
+    InlineStream st(rng);
     int64_t i = n - 1;
     while (i >= 1) {
         const int64_t cnt = i < BLK ? i : BLK;
@@ -218,24 +247,59 @@ extern "C" int ppo2hip_shuffle_i64(ppo2hip_rng *rng, int64_t *inds, int64_t n) {
 extern "C" int ppo2hip_shuffle_i32(ppo2hip_rng *rng, int32_t *inds, int64_t n) { return shuffle_impl(rng, inds, n); }
 
 // ---------------------------------------------------------------------------------------
-// Two-stage pipeline over all epochs of an update
+// Pipeline over all epochs of an update
+//
+// Shuffling an array x in place leaves x o sigma, where sigma is what the same swaps make of
+// the identity.  So the epochs' Fisher-Yates passes, which the reference chains through one
+// array (epoch e shuffles epoch e-1's order), split into
+//   draw    : one thread, the only consumer of the generator: swap targets of every epoch in
+//             stream order;
+//   swap    : sigma_e from the identity, one worker per epoch in flight (they do not depend on
+//             each other), started when the epoch's targets are complete;
+//   compose : out_e = out_{e-1}[sigma_e] (out_0 = sigma_0), a gather, chained in epoch order; in
+//             "relative" mode the sigma_e themselves are handed out and the caller composes
+//             (ppo2hip_compose_i32 does it on the device).
 // ---------------------------------------------------------------------------------------
 struct ppo2hip_perm {
+    static constexpr int kMaxWorkers = 4;
     ppo2hip_rng *rng = nullptr;
     int64_t n = 0;
     int max_epochs = 0;
-    std::vector<uint32_t> js;          // [max_epochs][n-1] swap targets in draw order
-    std::vector<int32_t> x;            // running permutation (epoch e shuffles epoch e-1's order)
-    std::vector<int32_t *> out;        // caller's per-epoch destinations
+    int nworkers = 1;
+    std::vector<uint32_t> js;              // [max_epochs][n-1] swap targets in draw order
+    std::vector<int32_t> sigma[kMaxWorkers];
+    std::vector<int32_t *> out;            // caller's per-epoch destinations
     int nepochs = 0;
-    std::atomic<int64_t> drawn{0};     // swap targets published so far (this job)
-    std::atomic<int> epochs_done{0};
+    bool relative = false;                 // out[e] = sigma_e (the caller composes) instead of the running order
+    int epochs_drawn = 0;                  // epochs whose swap targets are complete (guarded by mu)
+    std::vector<char> epoch_done;          // out[e] complete (guarded by mu; epochs finish in any order)
     std::atomic<bool> draw_done{true};
-    uint64_t job = 0, job_draw = 0, job_swap = 0;
+    uint64_t job = 0, job_draw = 0, job_swap[kMaxWorkers] = {0, 0, 0, 0};
+    int workers_idle = 0;                  // swap workers that finished the current job
     bool quit = false;
     std::mutex mu;
     std::condition_variable cv_start, cv_done;
-    std::thread t_draw, t_swap;
+    std::thread t_draw, t_swap[kMaxWorkers];
+
+    void draw_epochs() {
+        const int64_t per = n - 1;
+        InlineStream st(rng);              // hands its position back to the generator when it goes out of scope
+        constexpr int64_t BLK = 8192;
+        for (int e = 0; e < nepochs; e++) {
+            int64_t i = n - 1;
+            uint32_t *dst = js.data() + (size_t)e * per;
+            while (i >= 1) {
+                const int64_t cnt = i < BLK ? i : BLK;
+                draw_targets(st, i, i - cnt + 1, dst + (per - i));
+                i -= cnt;
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                epochs_drawn = e + 1;
+            }
+            cv_done.notify_all();
+        }
+    }
 
     void draw_loop() {
         for (;;) {
@@ -245,19 +309,7 @@ struct ppo2hip_perm {
                 if (quit) return;
                 job_draw = job;
             }
-            const int64_t per = n - 1;
-            Stream st(rng);
-            constexpr int64_t BLK = 8192;
-            for (int e = 0; e < nepochs; e++) {
-                int64_t i = n - 1;
-                uint32_t *dst = js.data() + (size_t)e * per;
-                while (i >= 1) {
-                    const int64_t cnt = i < BLK ? i : BLK;
-                    draw_targets(st, i, i - cnt + 1, dst + (per - i));
-                    i -= cnt;
-                    drawn.store((int64_t)e * per + (per - i), std::memory_order_release);
-                }
-            }
+            draw_epochs();
             {
                 std::lock_guard<std::mutex> lk(mu);
                 draw_done.store(true);
@@ -266,36 +318,48 @@ struct ppo2hip_perm {
         }
     }
 
-    void swap_loop() {
+    void swap_loop(int w) {
         for (;;) {
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_start.wait(lk, [&] { return quit || job_swap != job; });
+                cv_start.wait(lk, [&] { return quit || job_swap[w] != job; });
                 if (quit) return;
-                job_swap = job;
+                job_swap[w] = job;
             }
             const int64_t per = n - 1;
-            for (int64_t k = 0; k < n; k++) x[k] = (int32_t)k;
-            for (int e = 0; e < nepochs; e++) {
-                int64_t done = 0;
-                const uint32_t *src = js.data() + (size_t)e * per;
-                while (done < per) {
-                    int64_t avail = drawn.load(std::memory_order_acquire) - (int64_t)e * per;
-                    if (avail > per) avail = per;
-                    if (avail <= done) {
-                        std::this_thread::yield();
-                        continue;
-                    }
-                    apply_swaps(x.data(), (n - 1) - done, src + done, avail - done);
-                    done = avail;
+            for (int e = w; e < nepochs; e += nworkers) {
+                int32_t *sg = (relative || e == 0) ? out[e] : sigma[w].data();
+                for (int64_t k = 0; k < n; k++) sg[k] = (int32_t)k;
+                {   // sleep until this epoch's targets are all there: a worker that polls for partial
+                    // batches costs the drawing thread more than the overlap returns
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_done.wait(lk, [&] { return epochs_drawn > e; });
                 }
-                std::memcpy(out[e], x.data(), (size_t)n * sizeof(int32_t));
+                apply_swaps(sg, n - 1, js.data() + (size_t)e * per, per);
+                if (!relative && e > 0) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_done.wait(lk, [&] { return epoch_done[e - 1] != 0; });
+                    }
+                    const int32_t *prev = out[e - 1];
+                    int32_t *dst = out[e];
+                    constexpr int AHEAD = 32;
+                    for (int64_t k = 0; k < n; k++) {
+                        if (k + AHEAD < n) __builtin_prefetch(&prev[sg[k + AHEAD]], 0, 1);
+                        dst[k] = prev[sg[k]];
+                    }
+                }
                 {
                     std::lock_guard<std::mutex> lk(mu);
-                    epochs_done.store(e + 1);
+                    epoch_done[e] = 1;
                 }
                 cv_done.notify_all();
             }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                workers_idle++;
+            }
+            cv_done.notify_all();
         }
     }
 };
@@ -309,11 +373,16 @@ extern "C" ppo2hip_perm *ppo2hip_perm_create(ppo2hip_rng *rng, int64_t n, int ma
     p->rng = rng;
     p->n = n;
     p->max_epochs = max_epochs;
+    p->nworkers = max_epochs < ppo2hip_perm::kMaxWorkers ? max_epochs : ppo2hip_perm::kMaxWorkers;
+    p->workers_idle = p->nworkers;
     p->js.resize((size_t)max_epochs * (size_t)(n > 1 ? n - 1 : 1) + 16);
-    p->x.resize((size_t)n);
     p->out.resize(max_epochs);
+    p->epoch_done.assign(max_epochs, 0);
     p->t_draw = std::thread([p] { p->draw_loop(); });
-    p->t_swap = std::thread([p] { p->swap_loop(); });
+    for (int w = 0; w < p->nworkers; w++) {
+        p->sigma[w].resize((size_t)n);
+        p->t_swap[w] = std::thread([p, w] { p->swap_loop(w); });
+    }
     return p;
 }
 
@@ -328,11 +397,11 @@ extern "C" void ppo2hip_perm_destroy(ppo2hip_perm *p) {
     }
     p->cv_start.notify_all();
     p->t_draw.join();
-    p->t_swap.join();
+    for (int w = 0; w < p->nworkers; w++) p->t_swap[w].join();
     delete p;
 }
 
-extern "C" int ppo2hip_perm_begin(ppo2hip_perm *p, int nepochs, int32_t *const *out) {
+static int perm_begin(ppo2hip_perm *p, int nepochs, int32_t *const *out, bool relative) {
     if (!p || !out || nepochs < 1 || nepochs > p->max_epochs) {
         ppo2hip::set_error("perm_begin: bad argument");
         return PPO2HIP_EINVAL;
@@ -347,14 +416,23 @@ extern "C" int ppo2hip_perm_begin(ppo2hip_perm *p, int nepochs, int32_t *const *
     {
         std::lock_guard<std::mutex> lk(p->mu);
         p->nepochs = nepochs;
+        p->relative = relative;
         for (int e = 0; e < nepochs; e++) p->out[e] = out[e];
-        p->drawn.store(0);
-        p->epochs_done.store(0);
+        p->epochs_drawn = 0;
+        std::fill(p->epoch_done.begin(), p->epoch_done.end(), 0);
         p->draw_done.store(false);
+        p->workers_idle = 0;
         p->job++;
     }
     p->cv_start.notify_all();
     return PPO2HIP_OK;
+}
+
+extern "C" int ppo2hip_perm_begin(ppo2hip_perm *p, int nepochs, int32_t *const *out) {
+    return perm_begin(p, nepochs, out, false);
+}
+extern "C" int ppo2hip_perm_begin_relative(ppo2hip_perm *p, int nepochs, int32_t *const *out) {
+    return perm_begin(p, nepochs, out, true);
 }
 
 extern "C" int ppo2hip_perm_wait(ppo2hip_perm *p, int epoch) {
@@ -363,7 +441,7 @@ extern "C" int ppo2hip_perm_wait(ppo2hip_perm *p, int epoch) {
         return PPO2HIP_EINVAL;
     }
     std::unique_lock<std::mutex> lk(p->mu);
-    p->cv_done.wait(lk, [&] { return p->epochs_done.load() > epoch; });
+    p->cv_done.wait(lk, [&] { return p->epoch_done[epoch] != 0; });
     return PPO2HIP_OK;
 }
 
@@ -373,6 +451,6 @@ extern "C" int ppo2hip_perm_wait_all(ppo2hip_perm *p) {
         return PPO2HIP_EINVAL;
     }
     std::unique_lock<std::mutex> lk(p->mu);
-    p->cv_done.wait(lk, [&] { return p->draw_done.load() && p->epochs_done.load() >= p->nepochs; });
+    p->cv_done.wait(lk, [&] { return p->draw_done.load() && p->workers_idle == p->nworkers; });
     return PPO2HIP_OK;
 }

@@ -221,8 +221,11 @@ class PermPipeline:
         if h:
             lib.ppo2hip_perm_destroy(h)
 
-    def begin(self, nepochs):
-        check(lib.ppo2hip_perm_begin(self._h, int(nepochs), self._ptrs), "perm_begin")
+    def begin(self, nepochs, relative=False):
+        """Start the job; with ``relative`` the buffers receive each epoch's own permutation of
+        arange(n), to be chained with :func:`compose` on the device."""
+        fn = lib.ppo2hip_perm_begin_relative if relative else lib.ppo2hip_perm_begin
+        check(fn(self._h, int(nepochs), self._ptrs), "perm_begin")
 
     def wait(self, epoch):
         check(lib.ppo2hip_perm_wait(self._h, int(epoch)), "perm_wait")
@@ -230,6 +233,17 @@ class PermPipeline:
 
     def wait_all(self):
         check(lib.ppo2hip_perm_wait_all(self._h), "perm_wait_all")
+
+
+def compose(prev, sigma, out):
+    """out[k] = prev[sigma[k]] on the device (int32): the minibatch order after one more shuffle."""
+    for t, name in ((prev, "prev"), (sigma, "sigma"), (out, "out")):
+        _dev(t, torch.int32, name)
+    n = sigma.numel()
+    if prev.numel() != n or out.numel() != n:
+        raise ValueError("compose: prev, sigma and out must hold the same number of entries")
+    check(lib.ppo2hip_compose_i32(_ptr(prev), _ptr(sigma), _ptr(out), n, _stream()), "compose")
+    return out
 
 
 # --------------------------------------------------------------------------------------
@@ -404,6 +418,36 @@ def adam_step(params, grads, m, v, lr, t, scratch, max_grad_norm=0.0, grad_scale
     check(lib.ppo2hip_adam_step(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), P, float(lr), int(t), beta1, beta2,
                                 epsilon, float(grad_scale), float(max_grad_norm or 0.0), _ptr(scratch), _stream()),
           "adam_step")
+
+
+def ppo_epoch(spec, loss_desc, params, grads, m, v, rollout, idx, nbatch_train, stats, cliprange, lr, t_first,
+              losses, workspace, adam_scratch, max_grad_norm=0.0, beta1=0.9, beta2=0.999, epsilon=1e-5):
+    """All minibatches of one epoch, gradient + Adam each, in one library call (single process)."""
+    for x, name in ((params, "params"), (grads, "grads"), (m, "m"), (v, "v"), (losses, "losses")):
+        _dev(x, torch.float32, name)
+    _dev(idx, torch.int32, "idx")
+    P, N = spec.nparams, idx.numel()
+    if params.numel() != P or grads.numel() != P or m.numel() != P or v.numel() != P:
+        raise ValueError("params/grads/m/v must have %d entries" % P)
+    if N % nbatch_train != 0:
+        raise ValueError("idx must hold a whole number of minibatches")
+    nmb = N // nbatch_train
+    if losses.numel() < 8 * nmb:
+        raise ValueError("losses needs 8 entries per minibatch")
+    if stats is not None:
+        _dev(stats, torch.float64, "stats")
+        if stats.numel() < 3 * nmb:
+            raise ValueError("stats needs 3 entries per minibatch")
+    have = workspace.numel() * workspace.element_size()
+    if have < spec.grad_workspace_bytes(nbatch_train):
+        raise ValueError("grad workspace too small")
+    if adam_scratch.numel() * adam_scratch.element_size() < lib.ppo2hip_adam_scratch_bytes(P):
+        raise ValueError("adam scratch too small")
+    check(lib.ppo2hip_ppo_epoch(ctypes.byref(spec.desc), ctypes.byref(loss_desc), _ptr(params), _ptr(grads), _ptr(m),
+                                _ptr(v), ctypes.byref(rollout.c), _ptr(idx), N, int(nbatch_train), _ptr(stats),
+                                float(cliprange), float(lr), int(t_first), beta1, beta2, epsilon,
+                                float(max_grad_norm or 0.0), _ptr(losses), _ptr(workspace), have, _ptr(adam_scratch),
+                                _stream()), "ppo_epoch")
 
 
 def gemm(A, B):

@@ -181,6 +181,7 @@ class Model(object):
             self._pp = hip.PermPipeline(self._shuffler, N, noptepochs)
             self._pp_key = key
             self._idx_dev = [torch.empty(N, dtype=torch.int32, device=self.device) for _ in range(noptepochs)]
+            self._sig_dev = [torch.empty(N, dtype=torch.int32, device=self.device) for _ in range(noptepochs)]
             self._idx_free = [None] * noptepochs      # main-stream event: kernels reading _idx_dev[e] done
             self._copy_stream = torch.cuda.Stream(device=self.device)
             self._copy_last = None
@@ -193,7 +194,8 @@ class Model(object):
         every epoch) or :124-136 for recurrent policies (env sequences), drawn from the
         global ``np.random`` stream (or the model's own after ``seed_shuffle``).  The index
         lists are produced by the C++ pipeline while the GPU works on earlier epochs and
-        reach HBM on a side stream.  Nothing here waits for the GPU: the result is a device
+        reach HBM on a side stream (each epoch's permutation of arange(N) is uploaded and chained
+        onto the previous order by a device gather).  Nothing here waits for the GPU: the result is a device
         tensor holding the mean of the per-minibatch loss rows (:139).  ``events``: optional list
         that receives a (start, end) pair of timing events around every gradient evaluation.
         """
@@ -215,7 +217,7 @@ class Model(object):
                 self._copy_last.synchronize()      # pinned index buffers of the previous update are free
             if not self._own_stream:
                 self._shuffler.adopt_numpy()
-            pp.begin(noptepochs)
+            pp.begin(noptepochs, relative=True)
         else:
             envsperbatch = nbatch_train // T
             if envsperbatch < 1 or E % envsperbatch != 0:
@@ -236,7 +238,11 @@ class Model(object):
                 with torch.cuda.stream(self._copy_stream):
                     if self._idx_free[e] is not None:
                         self._copy_stream.wait_event(self._idx_free[e])
-                    d_idx.copy_(host_idx, non_blocking=True)
+                    if e == 0:
+                        d_idx.copy_(host_idx, non_blocking=True)
+                    else:       # this epoch's own permutation arrives; the running order is a device gather
+                        self._sig_dev[e].copy_(host_idx, non_blocking=True)
+                        hip.compose(self._idx_dev[e - 1], self._sig_dev[e], d_idx)
                     ev = torch.cuda.Event()
                     ev.record(self._copy_stream)
                 self._copy_last = ev
@@ -248,6 +254,17 @@ class Model(object):
                 d_idx = torch.from_numpy(flat).to(self.device)
                 d_envs = torch.from_numpy(envinds.copy()).to(self.device)
             stats = hip.adv_stats(ro.advs, d_idx, nbatch_train, nmb, T, E, stat_ws)
+            if comm is None and not spec.recurrent and events is None:
+                # single process: the whole epoch (gradient + Adam per minibatch) is one library call
+                hip.ppo_epoch(spec, self.loss_desc, self.arena.theta, self.grads, self.adam_m, self.adam_v, rref, d_idx,
+                              nbatch_train, stats, cliprange, lr, self.adam_t + 1, self._losses[row:row + nmb], ws,
+                              self._adam_scratch, max_grad_norm=self.max_grad_norm)
+                self.adam_t += nmb
+                row += nmb
+                done = torch.cuda.Event()
+                done.record(main)
+                self._idx_free[e] = done
+                continue
             for j in range(nmb):
                 lo = j * nbatch_train
                 mb_envs = d_envs[j * envsperbatch:(j + 1) * envsperbatch] if spec.recurrent else None

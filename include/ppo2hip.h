@@ -107,7 +107,7 @@ int ppo2hip_rng_get_state(const ppo2hip_rng *rng, uint32_t *key, int *pos);
 int ppo2hip_shuffle_i64(ppo2hip_rng *rng, int64_t *inds, int64_t n);
 int ppo2hip_shuffle_i32(ppo2hip_rng *rng, int32_t *inds, int64_t n);
 
-/* The index lists of ALL epochs of one update, produced ahead of the GPU on two worker
+/* The index lists of ALL epochs of one update, produced ahead of the GPU on worker
  * threads: out[e] (HOST int32[n], e.g. pinned) receives `inds` after the (e+1)-th in-place
  * shuffle of arange(n) — exactly the successive states of `inds` in the epoch loop of
  * baselines/ppo2/ppo2.py:110-113.  One job at a time per handle; the rng must not be used
@@ -117,8 +117,14 @@ typedef struct ppo2hip_perm ppo2hip_perm;
 ppo2hip_perm *ppo2hip_perm_create(ppo2hip_rng *rng, int64_t n, int max_epochs);
 void ppo2hip_perm_destroy(ppo2hip_perm *p);
 int ppo2hip_perm_begin(ppo2hip_perm *p, int nepochs, int32_t *const *out);
+/* Same job, but out[e] receives sigma_e = the (e+1)-th shuffle applied to arange(n) on its own;
+ * the running order is inds_e = inds_{e-1}[sigma_e] (inds_0 = sigma_0), which
+ * ppo2hip_compose_i32 evaluates on the device.  Takes the gather off the host's critical path. */
+int ppo2hip_perm_begin_relative(ppo2hip_perm *p, int nepochs, int32_t *const *out);
 int ppo2hip_perm_wait(ppo2hip_perm *p, int epoch);   /* blocks until out[epoch] is complete */
 int ppo2hip_perm_wait_all(ppo2hip_perm *p);
+/* DEVICE pointers: out[k] = prev[sigma[k]] for k < n (out must not alias prev or sigma). */
+int ppo2hip_compose_i32(const int32_t *prev, const int32_t *sigma, int32_t *out, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------
  * Policy description and parameter arena
@@ -237,6 +243,19 @@ size_t ppo2hip_adam_scratch_bytes(int64_t P);
 int ppo2hip_adam_step(float *params, const float *grads, float *m, float *v, int64_t P, double lr,
                       int64_t t, double beta1, double beta2, double epsilon, double grad_scale,
                       double max_grad_norm, void *scratch, void *stream);
+
+/* One epoch's minibatch loop (baselines/ppo2/ppo2.py:114-118) of a feed-forward policy in one
+ * call, single process: for j < N / nbatch_train, ppo2hip_ppo_grad on idx[j*nbatch_train ..),
+ * normalised with stats[j] ({sum, sumsq, count} rows of ppo2hip_adv_stats, or NULL), losses to
+ * losses[j*8 ..), then ppo2hip_adam_step number t_first + j with grad_scale 1.  Saves the host the
+ * per-minibatch call overhead; the data-parallel path keeps the two calls apart because its
+ * gradient all-reduce goes between them. */
+int ppo2hip_ppo_epoch(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss, float *params,
+                      float *grads, float *adam_m, float *adam_v, const ppo2hip_rollout *rollout,
+                      const int32_t *idx, int64_t N, int64_t nbatch_train, const double *stats,
+                      float cliprange, double lr, int64_t t_first, double beta1, double beta2,
+                      double epsilon, double max_grad_norm, float *losses, void *workspace,
+                      size_t workspace_bytes, void *adam_scratch, void *stream);
 
 /* Plain fp32 GEMM on the MFMA path, exposed for tests: C[M,N] = A[M,K] * B[K,N] (row-major). */
 int ppo2hip_gemm_f32(const float *A, const float *B, float *C, int M, int N, int K, void *stream);

@@ -89,6 +89,49 @@ def test_permutation_pipeline_all_epochs(lib, golden):
         pp.begin(5)
 
 
+@pytest.mark.parametrize("n,nepochs", [(4096, 4), (70001, 7), (2, 3), (1, 2)])
+def test_permutation_pipeline_relative_mode(lib, n, nepochs):
+    """Each epoch's own permutation of arange(n), chained by a gather, is the in-place shuffle
+    sequence of baselines/ppo2/ppo2.py:110-113; the stream ends where NumPy's does."""
+    from baselines_amd.hip import LegacyShuffler, PermPipeline
+    sh = LegacyShuffler(77)
+    pp = PermPipeline(sh, n, nepochs, pinned=False)
+    pp.begin(nepochs, relative=True)
+    np.random.seed(77)
+    x = np.arange(n)
+    run = None
+    for e in range(nepochs):
+        sig = pp.wait(e).numpy().copy()
+        run = sig if run is None else run[sig]
+        np.random.shuffle(x)
+        np.testing.assert_array_equal(run, x)
+    pp.wait_all()
+    key, pos = sh.get_state()
+    st = np.random.get_state()
+    assert pos == st[2] and np.array_equal(key, st[1])
+
+
+def test_permutation_pipeline_many_jobs_out_of_order_completion(lib):
+    """Workers finish epochs in any order; wait(e) must see each one exactly when it is complete."""
+    from baselines_amd.hip import LegacyShuffler, PermPipeline
+    n, nepochs = 3001, 6
+    sh = LegacyShuffler(5)
+    pp = PermPipeline(sh, n, nepochs, pinned=False)
+    np.random.seed(5)
+    for job in range(40):
+        pp.begin(nepochs, relative=(job % 2 == 0))
+        x = np.arange(n)
+        run = None
+        for e in range(nepochs):
+            got = pp.wait(e).numpy().copy()
+            np.random.shuffle(x)
+            if job % 2 == 0:
+                run = got if run is None else run[got]
+                got = run
+            np.testing.assert_array_equal(got, x)
+        pp.wait_all()
+
+
 def test_rng_argument_checks(lib):
     from baselines_amd.hip import LegacyShuffler
     sh = LegacyShuffler(0)

@@ -145,3 +145,15 @@ def test_adv_stats(hip, dtype):
     for j in range(nmb):
         a = flat[perm[j * B:(j + 1) * B]].astype(np.float64)
         np.testing.assert_allclose(st[j], [a.sum(), (a * a).sum(), B], rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_compose_permutations(hip):
+    rng = np.random.RandomState(3)
+    n = 100003
+    prev, sig = rng.permutation(n).astype(np.int32), rng.permutation(n).astype(np.int32)
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    hip.compose(torch.from_numpy(prev).cuda(), torch.from_numpy(sig).cuda(), out)
+    np.testing.assert_array_equal(out.cpu().numpy(), prev[sig])
+    with pytest.raises(ValueError):
+        hip.compose(torch.from_numpy(prev).cuda(), torch.from_numpy(sig[:10]).cuda(), out)
