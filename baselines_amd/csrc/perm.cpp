@@ -14,15 +14,19 @@
 // threads and produces the cumulative shuffles of all epochs of an update ahead of the GPU,
 // so index generation overlaps the kernels of the previous epoch.
 #include <algorithm>
+#include <chrono>
+#include <memory>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
 #include <vector>
-#if defined(__AVX2__)
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
 #include <immintrin.h>
+#define PPO2HIP_X86 1
 #endif
 
 #include "common.hpp"
@@ -47,17 +51,6 @@ inline uint32_t twist(uint32_t u, uint32_t v) {
     return (y >> 1) ^ ((0u - (v & 1u)) & 0x9908b0dfu);
 }
 
-void regenerate(uint32_t *__restrict mt) {
-    int k = 0;
-    // 0..226 read only not-yet-rewritten words: independent iterations
-#pragma clang loop vectorize(assume_safety)
-    for (k = 0; k < N - M; k++) mt[k] = mt[k + M] ^ twist(mt[k], mt[k + 1]);
-    // 227..622 read words rewritten 227 iterations earlier: safe for any vector width <= 227
-#pragma clang loop vectorize(assume_safety)
-    for (k = N - M; k < N - 1; k++) mt[k] = mt[k + (M - N)] ^ twist(mt[k], mt[k + 1]);
-    mt[N - 1] = mt[M - 1] ^ twist(mt[N - 1], mt[0]);
-}
-
 inline uint32_t temper(uint32_t y) {
     y ^= y >> 11;
     y ^= (y << 7) & 0x9d2c5680u;
@@ -65,6 +58,46 @@ inline uint32_t temper(uint32_t y) {
     y ^= y >> 18;
     return y;
 }
+
+// Next 624-word block of the generator, and its tempered outputs.  The body is compiled twice on
+// x86: for the baseline vector width and for 512-bit vectors (picked at run time).
+//   words 0..226 read only not-yet-rewritten words: independent iterations;
+//   words 227..622 read words rewritten 227 iterations earlier: safe for any vector width <= 227.
+#define PPO2HIP_MT_BODY                                                                          \
+    if (advance) {                                                                               \
+        int k = 0;                                                                               \
+        _Pragma("clang loop vectorize(assume_safety)")                                           \
+        for (k = 0; k < N - M; k++) mt[k] = mt[k + M] ^ twist(mt[k], mt[k + 1]);                 \
+        _Pragma("clang loop vectorize(assume_safety)")                                           \
+        for (k = N - M; k < N - 1; k++) mt[k] = mt[k + (M - N)] ^ twist(mt[k], mt[k + 1]);       \
+        mt[N - 1] = mt[M - 1] ^ twist(mt[N - 1], mt[0]);                                         \
+    }                                                                                            \
+    if (out)                                                                                     \
+        for (int i = 0; i < N; i++) out[i] = temper(mt[i]);
+
+void next_block_base(uint32_t *__restrict mt, uint32_t *__restrict out, bool advance) { PPO2HIP_MT_BODY }
+#if defined(PPO2HIP_X86)
+__attribute__((target("avx512f,avx512vl,avx512bw,avx512dq")))
+void next_block_512(uint32_t *__restrict mt, uint32_t *__restrict out, bool advance) { PPO2HIP_MT_BODY }
+bool cpu_has_avx512() {
+    // PPO2HIP_NO_AVX512 (any value) keeps the baseline path, so that both can be tested on one machine
+    static const bool yes = !getenv("PPO2HIP_NO_AVX512") && __builtin_cpu_supports("avx512f") &&
+                            __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw") &&
+                            __builtin_cpu_supports("avx512dq");
+    return yes;
+}
+#else
+bool cpu_has_avx512() { return false; }
+#endif
+
+inline void next_block(uint32_t *mt, uint32_t *out, bool advance) {
+#if defined(PPO2HIP_X86)
+    if (cpu_has_avx512()) return next_block_512(mt, out, advance);
+#endif
+    next_block_base(mt, out, advance);
+}
+
+void regenerate(uint32_t *mt) { next_block(mt, nullptr, true); }
 
 // Buffered view of the stream, one 624-word block of tempered outputs at a time: out[pos ..)
 // are the unread outputs of the current block, refill() moves to the next block.
@@ -77,17 +110,14 @@ struct InlineStream {
         if (pos < N) fill();
     }
     ~InlineStream() { s->pos = pos; }
-    void fill() {
-        for (int i = 0; i < N; i++) buf[i] = temper(s->mt[i]);
-    }
+    void fill() { next_block(s->mt, buf, false); }
     void refill() {
-        regenerate(s->mt);
-        fill();
+        next_block(s->mt, buf, true);
         pos = 0;
     }
 };
 
-#if defined(__AVX2__)
+#if defined(PPO2HIP_X86) && defined(__AVX2__)
 // lane permutation that packs the lanes selected by an 8-bit mask to the front
 struct PackLut {
     alignas(32) uint32_t idx[256][8];
@@ -104,12 +134,42 @@ static const PackLut g_pack;
 #endif
 
 // Accepted swap targets for positions hi, hi-1, ..., lo (lo >= 1), written to js[0 .. hi-lo]
-// (up to 8 words of scratch may be written past that).  Eight candidates are classified at
+// (up to 16 words of scratch may be written past that).  Eight candidates are classified at
 // once: a masked value <= i-7 is accepted and one > i is rejected whatever the seven
 // decisions before it were, so unless a value falls in the 7-wide window between (about
 // 8 / 2^k of the blocks) the block is compacted with one vector permute; otherwise, and
 // near buffer or mask-range ends, candidates go through the scalar loop, in which the
 // accept test only steers an index increment (no data-dependent branch).
+#if defined(PPO2HIP_X86)
+// 64 candidates at a time on 512-bit vectors; same decisions as the 256-bit loop in draw_targets
+// (a value <= i-63 is accepted, one > i rejected, anything between ends the run).  Returns the
+// advanced (p, i, w) through the references.
+__attribute__((target("avx512f,avx512vl,avx512bw,avx512dq")))
+void draw_run_512(const uint32_t *out, int &p, int64_t &i, int64_t stop, uint32_t mask, uint32_t *js, int64_t &w) {
+    const __m512i vmask = _mm512_set1_epi32((int)mask);
+    while (p + 64 <= N && i - 63 >= stop) {
+        const __m512i t_lo = _mm512_set1_epi32((int)(i - 63)), t_hi = _mm512_set1_epi32((int)i);
+        __m512i v[4];
+        __mmask16 acc[4], amb = 0;
+        for (int b = 0; b < 4; b++) {
+            v[b] = _mm512_and_si512(_mm512_loadu_si512((const void *)(out + p + 16 * b)), vmask);
+            const __mmask16 gt_lo = _mm512_cmpgt_epi32_mask(v[b], t_lo);
+            amb |= gt_lo ^ _mm512_cmpgt_epi32_mask(v[b], t_hi);
+            acc[b] = (__mmask16)~gt_lo;
+        }
+        if (amb) break;
+        const int64_t w0 = w;
+        for (int b = 0; b < 4; b++) {
+            // compress in a register, then a plain store (the memory form of the compress is slow on some cores)
+            _mm512_storeu_si512((void *)(js + w), _mm512_maskz_compress_epi32(acc[b], v[b]));
+            w += __builtin_popcount((unsigned)acc[b]);
+        }
+        i -= w - w0;
+        p += 64;
+    }
+}
+#endif
+
 template <class S>
 void draw_targets(S &st, int64_t hi, int64_t lo, uint32_t *js) {
     int64_t i = hi;
@@ -122,7 +182,10 @@ void draw_targets(S &st, int64_t hi, int64_t lo, uint32_t *js) {
         const int64_t lim_mask = (int64_t)(mask >> 1) + 1;
         const int64_t stop = lim_mask > lo ? lim_mask : lo;
         int p = st.pos;
-#if defined(__AVX2__)
+#if defined(PPO2HIP_X86)
+        if (mask <= 0x7fffffffu && cpu_has_avx512()) draw_run_512(st.out, p, i, stop, mask, js, w);
+#endif
+#if defined(PPO2HIP_X86) && defined(__AVX2__)
         if (mask <= 0x7fffffffu) {
             const __m256i vmask = _mm256_set1_epi32((int)mask);
             // 64 candidates against thresholds fixed on entry: the k-th one's true bound lies in
@@ -251,96 +314,92 @@ extern "C" int ppo2hip_shuffle_i32(ppo2hip_rng *rng, int32_t *inds, int64_t n) {
 //
 // Shuffling an array x in place leaves x o sigma, where sigma is what the same swaps make of
 // the identity.  So the epochs' Fisher-Yates passes, which the reference chains through one
-// array (epoch e shuffles epoch e-1's order), split into
-//   draw    : one thread, the only consumer of the generator: swap targets of every epoch in
-//             stream order;
-//   swap    : sigma_e from the identity, one worker per epoch in flight (they do not depend on
-//             each other), started when the epoch's targets are complete;
+// array (epoch e shuffles epoch e-1's order), split into per-epoch jobs that workers take in
+// turn (epoch e goes to worker e mod W):
+//   draw    : the worker whose turn it is owns the generator and draws its epoch's swap targets,
+//             in stream order, into a buffer of its own, then passes the generator on — the only
+//             data that moves between cores is the 2.5 KB generator state;
+//   swap    : sigma_e from the identity with those targets, while the next worker draws;
 //   compose : out_e = out_{e-1}[sigma_e] (out_0 = sigma_0), a gather, chained in epoch order; in
 //             "relative" mode the sigma_e themselves are handed out and the caller composes
 //             (ppo2hip_compose_i32 does it on the device).
 // ---------------------------------------------------------------------------------------
 struct ppo2hip_perm {
     static constexpr int kMaxWorkers = 4;
+    int spin_job_us = 0, spin_stage_us = 2000;   // how long a wait polls before it blocks (TEMP: env-tunable)
     ppo2hip_rng *rng = nullptr;
     int64_t n = 0;
     int max_epochs = 0;
     int nworkers = 1;
-    std::vector<uint32_t> js;              // [max_epochs][n-1] swap targets in draw order
+    std::vector<uint32_t> js[kMaxWorkers];     // the worker's swap targets in draw order, [n-1]
     std::vector<int32_t> sigma[kMaxWorkers];
     std::vector<int32_t *> out;            // caller's per-epoch destinations
     int nepochs = 0;
     bool relative = false;                 // out[e] = sigma_e (the caller composes) instead of the running order
-    int epochs_drawn = 0;                  // epochs whose swap targets are complete (guarded by mu)
-    std::vector<char> epoch_done;          // out[e] complete (guarded by mu; epochs finish in any order)
-    std::atomic<bool> draw_done{true};
-    uint64_t job = 0, job_draw = 0, job_swap[kMaxWorkers] = {0, 0, 0, 0};
-    int workers_idle = 0;                  // swap workers that finished the current job
-    bool quit = false;
+    // progress flags: written under mu (so that blocked waiters can be notified), read lock-free by pollers
+    std::atomic<uint64_t> job{0};
+    std::atomic<int> epochs_drawn{0};      // epochs drawn so far = the epoch whose worker owns the generator
+    std::unique_ptr<std::atomic<char>[]> epoch_done;   // out[e] complete (epochs finish in any order)
+    std::atomic<int> workers_idle{0};      // workers that finished the current job
+    std::atomic<bool> quit{false};
     std::mutex mu;
-    std::condition_variable cv_start, cv_done;
-    std::thread t_draw, t_swap[kMaxWorkers];
+    std::condition_variable cv;
+    std::thread t_work[kMaxWorkers];
 
-    void draw_epochs() {
-        const int64_t per = n - 1;
+    // Wait for pred (a function of the flags above).  The stages of a job follow each other within
+    // a fraction of a millisecond, and a thread that blocks gives its CPU away and restarts cold (on
+    // a virtual machine that alone costs as much as a stage), so poll first and block only when
+    // nothing comes for a while, e.g. between updates of a slow environment.
+    template <class Pred>
+    void await(Pred pred, int kSpinMicros) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (kSpinMicros > 0)
+        for (int k = 1;; k++) {
+            if (pred()) return;
+#if defined(PPO2HIP_X86)
+            for (int q = 0; q < 32; q++) _mm_pause();
+#endif
+            if ((k & 31) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kSpinMicros)) break;
+        }
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, pred);
+    }
+    template <class F>
+    void publish(F set) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            set();
+        }
+        cv.notify_all();
+    }
+
+    void draw_epoch(uint32_t *dst) {
         InlineStream st(rng);              // hands its position back to the generator when it goes out of scope
         constexpr int64_t BLK = 8192;
-        for (int e = 0; e < nepochs; e++) {
-            int64_t i = n - 1;
-            uint32_t *dst = js.data() + (size_t)e * per;
-            while (i >= 1) {
-                const int64_t cnt = i < BLK ? i : BLK;
-                draw_targets(st, i, i - cnt + 1, dst + (per - i));
-                i -= cnt;
-            }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                epochs_drawn = e + 1;
-            }
-            cv_done.notify_all();
+        const int64_t per = n - 1;
+        int64_t i = n - 1;
+        while (i >= 1) {
+            const int64_t cnt = i < BLK ? i : BLK;
+            draw_targets(st, i, i - cnt + 1, dst + (per - i));
+            i -= cnt;
         }
     }
 
-    void draw_loop() {
+    void work_loop(int w) {
+        uint64_t seen = 0;
         for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_start.wait(lk, [&] { return quit || job_draw != job; });
-                if (quit) return;
-                job_draw = job;
-            }
-            draw_epochs();
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                draw_done.store(true);
-            }
-            cv_done.notify_all();
-        }
-    }
-
-    void swap_loop(int w) {
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_start.wait(lk, [&] { return quit || job_swap[w] != job; });
-                if (quit) return;
-                job_swap[w] = job;
-            }
-            const int64_t per = n - 1;
+            await([&] { return quit.load() || job.load(std::memory_order_acquire) != seen; }, spin_job_us);
+            if (quit.load()) return;
+            seen = job.load(std::memory_order_acquire);
             for (int e = w; e < nepochs; e += nworkers) {
                 int32_t *sg = (relative || e == 0) ? out[e] : sigma[w].data();
                 for (int64_t k = 0; k < n; k++) sg[k] = (int32_t)k;
-                {   // sleep until this epoch's targets are all there: a worker that polls for partial
-                    // batches costs the drawing thread more than the overlap returns
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv_done.wait(lk, [&] { return epochs_drawn > e; });
-                }
-                apply_swaps(sg, n - 1, js.data() + (size_t)e * per, per);
+                await([&] { return epochs_drawn.load(std::memory_order_acquire) == e; }, spin_stage_us);    // the generator is ours
+                draw_epoch(js[w].data());
+                publish([&] { epochs_drawn.store(e + 1, std::memory_order_release); });      // ... and the next worker's
+                apply_swaps(sg, n - 1, js[w].data(), n - 1);
                 if (!relative && e > 0) {
-                    {
-                        std::unique_lock<std::mutex> lk(mu);
-                        cv_done.wait(lk, [&] { return epoch_done[e - 1] != 0; });
-                    }
+                    await([&] { return epoch_done[e - 1].load(std::memory_order_acquire) != 0; }, spin_stage_us);
                     const int32_t *prev = out[e - 1];
                     int32_t *dst = out[e];
                     constexpr int AHEAD = 32;
@@ -349,17 +408,9 @@ struct ppo2hip_perm {
                         dst[k] = prev[sg[k]];
                     }
                 }
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    epoch_done[e] = 1;
-                }
-                cv_done.notify_all();
+                publish([&] { epoch_done[e].store(1, std::memory_order_release); });
             }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                workers_idle++;
-            }
-            cv_done.notify_all();
+            publish([&] { workers_idle.fetch_add(1, std::memory_order_release); });
         }
     }
 };
@@ -374,14 +425,16 @@ extern "C" ppo2hip_perm *ppo2hip_perm_create(ppo2hip_rng *rng, int64_t n, int ma
     p->n = n;
     p->max_epochs = max_epochs;
     p->nworkers = max_epochs < ppo2hip_perm::kMaxWorkers ? max_epochs : ppo2hip_perm::kMaxWorkers;
-    p->workers_idle = p->nworkers;
-    p->js.resize((size_t)max_epochs * (size_t)(n > 1 ? n - 1 : 1) + 16);
+    p->workers_idle.store(p->nworkers);
+    if (getenv("PPO2HIP_SPIN_JOB_US")) p->spin_job_us = atoi(getenv("PPO2HIP_SPIN_JOB_US"));
+    if (getenv("PPO2HIP_SPIN_STAGE_US")) p->spin_stage_us = atoi(getenv("PPO2HIP_SPIN_STAGE_US"));
     p->out.resize(max_epochs);
-    p->epoch_done.assign(max_epochs, 0);
-    p->t_draw = std::thread([p] { p->draw_loop(); });
+    p->epoch_done.reset(new std::atomic<char>[max_epochs]);
+    for (int e = 0; e < max_epochs; e++) p->epoch_done[e].store(0);
     for (int w = 0; w < p->nworkers; w++) {
+        p->js[w].resize((size_t)(n > 1 ? n - 1 : 1) + 16);
         p->sigma[w].resize((size_t)n);
-        p->t_swap[w] = std::thread([p, w] { p->swap_loop(w); });
+        p->t_work[w] = std::thread([p, w] { p->work_loop(w); });
     }
     return p;
 }
@@ -391,13 +444,8 @@ extern "C" int ppo2hip_perm_wait_all(ppo2hip_perm *p);
 extern "C" void ppo2hip_perm_destroy(ppo2hip_perm *p) {
     if (!p) return;
     ppo2hip_perm_wait_all(p);
-    {
-        std::lock_guard<std::mutex> lk(p->mu);
-        p->quit = true;
-    }
-    p->cv_start.notify_all();
-    p->t_draw.join();
-    for (int w = 0; w < p->nworkers; w++) p->t_swap[w].join();
+    p->publish([&] { p->quit.store(true); });
+    for (int w = 0; w < p->nworkers; w++) p->t_work[w].join();
     delete p;
 }
 
@@ -413,18 +461,15 @@ static int perm_begin(ppo2hip_perm *p, int nepochs, int32_t *const *out, bool re
         }
     int rc = ppo2hip_perm_wait_all(p);   // one job at a time: the previous one must have drained
     if (rc) return rc;
-    {
-        std::lock_guard<std::mutex> lk(p->mu);
+    p->publish([&] {
         p->nepochs = nepochs;
         p->relative = relative;
         for (int e = 0; e < nepochs; e++) p->out[e] = out[e];
-        p->epochs_drawn = 0;
-        std::fill(p->epoch_done.begin(), p->epoch_done.end(), 0);
-        p->draw_done.store(false);
-        p->workers_idle = 0;
-        p->job++;
-    }
-    p->cv_start.notify_all();
+        p->epochs_drawn.store(0);
+        for (int e = 0; e < p->max_epochs; e++) p->epoch_done[e].store(0);
+        p->workers_idle.store(0);
+        p->job.fetch_add(1, std::memory_order_release);
+    });
     return PPO2HIP_OK;
 }
 
@@ -440,8 +485,7 @@ extern "C" int ppo2hip_perm_wait(ppo2hip_perm *p, int epoch) {
         ppo2hip::set_error("perm_wait: bad epoch");
         return PPO2HIP_EINVAL;
     }
-    std::unique_lock<std::mutex> lk(p->mu);
-    p->cv_done.wait(lk, [&] { return p->epoch_done[epoch] != 0; });
+    p->await([&] { return p->epoch_done[epoch].load(std::memory_order_acquire) != 0; }, p->spin_stage_us);
     return PPO2HIP_OK;
 }
 
@@ -450,7 +494,6 @@ extern "C" int ppo2hip_perm_wait_all(ppo2hip_perm *p) {
         ppo2hip::set_error("perm_wait_all: null handle");
         return PPO2HIP_EINVAL;
     }
-    std::unique_lock<std::mutex> lk(p->mu);
-    p->cv_done.wait(lk, [&] { return p->draw_done.load() && p->workers_idle == p->nworkers; });
+    p->await([&] { return p->workers_idle.load(std::memory_order_acquire) == p->nworkers; }, p->spin_stage_us);
     return PPO2HIP_OK;
 }

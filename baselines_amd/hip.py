@@ -204,28 +204,32 @@ class LegacyShuffler:
 
 
 class PermPipeline:
-    """All epochs' index lists of an update, generated in the background (two C++ worker
-    threads) into pinned host buffers, from a LegacyShuffler's stream."""
+    """All epochs' index lists of an update, generated in the background (C++ worker threads)
+    into pinned host buffers, from a LegacyShuffler's stream.  ``nsets`` buffer sets let a job
+    for the next update be started while copies out of the previous set are still queued."""
 
-    def __init__(self, shuffler, n, max_epochs, pinned=True):
+    def __init__(self, shuffler, n, max_epochs, pinned=True, nsets=1):
         self.shuffler, self.n, self.max_epochs = shuffler, int(n), int(max_epochs)
         self._h = lib.ppo2hip_perm_create(shuffler._h, self.n, self.max_epochs)
         if not self._h:
             check(_lib.EINVAL, "perm_create")
         pin = bool(pinned and torch.cuda.is_available())
-        self.bufs = [torch.empty(self.n, dtype=torch.int32, pin_memory=pin) for _ in range(self.max_epochs)]
-        self._ptrs = (ctypes.c_void_p * self.max_epochs)(*[b.data_ptr() for b in self.bufs])
+        self.sets = [[torch.empty(self.n, dtype=torch.int32, pin_memory=pin) for _ in range(self.max_epochs)]
+                     for _ in range(int(nsets))]
+        self._set_ptrs = [(ctypes.c_void_p * self.max_epochs)(*[b.data_ptr() for b in s]) for s in self.sets]
+        self.bufs = self.sets[0]
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
             lib.ppo2hip_perm_destroy(h)
 
-    def begin(self, nepochs, relative=False):
+    def begin(self, nepochs, relative=False, buffer_set=0):
         """Start the job; with ``relative`` the buffers receive each epoch's own permutation of
         arange(n), to be chained with :func:`compose` on the device."""
         fn = lib.ppo2hip_perm_begin_relative if relative else lib.ppo2hip_perm_begin
-        check(fn(self._h, int(nepochs), self._ptrs), "perm_begin")
+        check(fn(self._h, int(nepochs), self._set_ptrs[buffer_set]), "perm_begin")
+        self.bufs = self.sets[buffer_set]
 
     def wait(self, epoch):
         check(lib.ppo2hip_perm_wait(self._h, int(epoch)), "perm_wait")

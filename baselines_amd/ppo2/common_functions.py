@@ -178,16 +178,28 @@ class Model(object):
             if not hasattr(self, "_shuffler"):
                 self._shuffler = hip.LegacyShuffler(0)
                 self._own_stream = False
-            self._pp = hip.PermPipeline(self._shuffler, N, noptepochs)
+            self._pp = hip.PermPipeline(self._shuffler, N, noptepochs, nsets=2)
             self._pp_key = key
+            self._pp_set = 0               # buffer set of the job in flight / last used
+            self._pp_ahead = False         # a job for the coming update is already running
+            self._set_copied = [None, None]   # last copy event out of each buffer set
             self._idx_dev = [torch.empty(N, dtype=torch.int32, device=self.device) for _ in range(noptepochs)]
             self._sig_dev = [torch.empty(N, dtype=torch.int32, device=self.device) for _ in range(noptepochs)]
             self._idx_free = [None] * noptepochs      # main-stream event: kernels reading _idx_dev[e] done
             self._copy_stream = torch.cuda.Stream(device=self.device)
-            self._copy_last = None
         return self._pp
 
-    def train_on_rollout(self, lr, cliprange, ro, noptepochs, nbatch_train, events=None):
+    def _begin_index_job(self, pp, noptepochs):
+        """Start generating an update's index lists into the buffer set not used by the last job."""
+        s = self._pp_set ^ 1
+        if self._set_copied[s] is not None:
+            self._set_copied[s].synchronize()      # copies out of that set (two jobs ago) have run
+        if not self._own_stream:
+            self._shuffler.adopt_numpy()
+        pp.begin(noptepochs, relative=True, buffer_set=s)
+        self._pp_set = s
+
+    def train_on_rollout(self, lr, cliprange, ro, noptepochs, nbatch_train, events=None, more_updates=False):
         """All epochs x minibatches of one update from device-resident rollout buffers.
 
         Index generation follows baselines/ppo2/ppo2.py:110-116 (``inds`` shuffled in place
@@ -198,6 +210,10 @@ class Model(object):
         onto the previous order by a device gather).  Nothing here waits for the GPU: the result is a device
         tensor holding the mean of the per-minibatch loss rows (:139).  ``events``: optional list
         that receives a (start, end) pair of timing events around every gradient evaluation.
+        ``more_updates``: another update of the same shape follows; when the model owns its
+        shuffle stream (``seed_shuffle``) the next update's index lists are then generated
+        ahead, while the GPU works through this one (the shared ``np.random`` stream is never
+        drawn from ahead of time: other users of it would see the draws reordered).
         """
         spec = self.spec
         T, E = ro.T, ro.E
@@ -213,11 +229,9 @@ class Model(object):
                 raise AssertionError("nbatch %% nbatch_train != 0")   # baselines/ppo2/ppo2.py:74
             nmb = N // nbatch_train
             pp = self._index_pipeline(N, noptepochs)
-            if self._copy_last is not None:
-                self._copy_last.synchronize()      # pinned index buffers of the previous update are free
-            if not self._own_stream:
-                self._shuffler.adopt_numpy()
-            pp.begin(noptepochs, relative=True)
+            if not self._pp_ahead:
+                self._begin_index_job(pp, noptepochs)
+            self._pp_ahead = False
         else:
             envsperbatch = nbatch_train // T
             if envsperbatch < 1 or E % envsperbatch != 0:
@@ -245,7 +259,7 @@ class Model(object):
                         hip.compose(self._idx_dev[e - 1], self._sig_dev[e], d_idx)
                     ev = torch.cuda.Event()
                     ev.record(self._copy_stream)
-                self._copy_last = ev
+                self._set_copied[self._pp_set] = ev
                 main.wait_event(ev)
                 d_envs = None
             else:
@@ -288,6 +302,9 @@ class Model(object):
             pp.wait_all()
             if not self._own_stream:
                 self._shuffler.release_numpy()
+            elif more_updates:
+                self._begin_index_job(pp, noptepochs)
+                self._pp_ahead = True
         out = self._losses[:total, :5].double().sum(dim=0) / total
         if comm is not None:
             comm.allreduce_sum_(out)

@@ -74,7 +74,8 @@ def learn(*, policy, env, nsteps, total_timesteps, ent_coef, lr,
             ro.advs = compute_advs(max_return[:R], ro.values.reshape(N, R), ro.advs_ori.reshape(N, R), [], []) \
                 .reshape(ro.T, ro.E)
         if device_path:
-            lossvals = model.train_on_rollout(float(lrnow), float(cliprangenow), ro, noptepochs, nbatch_train).cpu().numpy()
+            lossvals = model.train_on_rollout(float(lrnow), float(cliprangenow), ro, noptepochs, nbatch_train,
+                                               more_updates=update < nupdates).cpu().numpy()
         else:
             # the reference's host loop (:109-137): shuffle, fancy-index gather, Model.train per minibatch
             advs_host = sf01_host(ro.advs)

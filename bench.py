@@ -169,7 +169,7 @@ def main():
         else:
             ro.advs = hip.compute_advs([200, 120, 0, 0, 0][:R], ro.values.reshape(N, R), ro.advs_ori.reshape(N, R)).reshape(T, E)
         return model.train_on_rollout(cfg["lr"], cfg["cliprange"], ro, cfg["noptepochs"], B,
-                                      events=None if events is None else events["grad"])
+                                      events=None if events is None else events["grad"], more_updates=True)
 
     def barrier():
         if world > 1:

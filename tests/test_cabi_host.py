@@ -132,6 +132,27 @@ def test_permutation_pipeline_many_jobs_out_of_order_completion(lib):
         pp.wait_all()
 
 
+def test_shuffle_without_avx512_in_a_fresh_process():
+    """The 256-bit draw path (taken on CPUs without AVX-512) against NumPy, whatever this machine has."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np\n"
+        "from baselines_amd.hip import LegacyShuffler, PermPipeline\n"
+        "for n in (1, 2, 3, 100, 4097, 300001):\n"
+        "    sh = LegacyShuffler(n); a = np.arange(n, dtype=np.int64); sh.shuffle(a)\n"
+        "    np.random.seed(n); b = np.arange(n); np.random.shuffle(b)\n"
+        "    assert np.array_equal(a, b), n\n"
+        "sh = LegacyShuffler(9); pp = PermPipeline(sh, 50000, 3, pinned=False); pp.begin(3)\n"
+        "np.random.seed(9); x = np.arange(50000)\n"
+        "for e in range(3):\n"
+        "    np.random.shuffle(x); assert np.array_equal(pp.wait(e).numpy(), x)\n"
+        "pp.wait_all(); print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PPO2HIP_NO_AVX512="1", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_rng_argument_checks(lib):
     from baselines_amd.hip import LegacyShuffler
     sh = LegacyShuffler(0)
