@@ -23,22 +23,43 @@ __global__ void sumsq_partial_kernel(const float *__restrict__ g, int64_t P, flo
 
 // npartial == 0 with clipping on: the arena is small, so every block sums the squares of the
 // WHOLE gradient itself (same order in every block, hence the same norm) and no separate
-// norm launch is needed.
+// norm launch is needed.  Loads are issued in batches so that a batch costs one round trip.
 __global__ void adam_kernel(float *__restrict__ theta, const float *__restrict__ g, float *__restrict__ m,
                             float *__restrict__ v, int64_t P, float a, float beta1, float beta2, float eps,
                             float gscale, float max_norm, const double *__restrict__ partial, int npartial,
                             float *__restrict__ header) {
     __shared__ float scale_s;
     __shared__ double red[17];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // this block's own elements: in flight while the norm is being summed
+    constexpr int U = 4;
+    const int64_t first = (int64_t)blockIdx.x * nt * U;
+    float gi[U], mi[U], vi[U], th[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int64_t i = first + (int64_t)u * nt + tid;
+        const bool ok = i < P;
+        gi[u] = ok ? g[i] : 0.f;
+        mi[u] = ok ? m[i] : 0.f;
+        vi[u] = ok ? v[i] : 0.f;
+        th[u] = ok ? theta[i] : 0.f;
+    }
     double own = 0.0;
     if (max_norm > 0.f && npartial == 0) {
-        for (int64_t i = threadIdx.x; i < P; i += blockDim.x) {
-            const double x = (double)(g[i] * gscale);
-            own += x * x;
+        constexpr int W = 8;
+        for (int64_t base = 0; base < P; base += (int64_t)nt * W) {
+            float x[W];
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                const int64_t i = base + (int64_t)w * nt + tid;
+                x[w] = i < P ? g[i] * gscale : 0.f;
+            }
+#pragma unroll
+            for (int w = 0; w < W; w++) own += (double)x[w] * (double)x[w];
         }
         own = block_sum(own, red);
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         float scale = gscale;
         if (max_norm > 0.f) {
             double ss = own;
@@ -53,13 +74,17 @@ __global__ void adam_kernel(float *__restrict__ theta, const float *__restrict__
     __syncthreads();
     const float scale = scale_s;
     const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * scale;
-        const float mi = beta1 * m[i] + omb1 * gi;
-        const float vi = beta2 * v[i] + omb2 * (gi * gi);
-        m[i] = mi;
-        v[i] = vi;
-        theta[i] += (-a) * mi / (sqrtf(vi) + eps);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int64_t i = first + (int64_t)u * nt + tid;
+        if (i < P) {
+            const float gs = gi[u] * scale;
+            const float m1 = beta1 * mi[u] + omb1 * gs;
+            const float v1 = beta2 * vi[u] + omb2 * (gs * gs);
+            m[i] = m1;
+            v[i] = v1;
+            theta[i] = th[u] + (-a) * m1 / (sqrtf(v1) + eps);
+        }
     }
 }
 
@@ -89,7 +114,8 @@ extern "C" int ppo2hip_adam_step(float *params, const float *grads, float *m, fl
         if (rc) return rc;
     }
     const double a = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
-    const int64_t nb = ceil_div(P, 1024) < 1024 ? ceil_div(P, 1024) : 1024;
+    const int64_t nb = ceil_div(P, 1024);      // 256 threads x 4 elements per block
+    PPO2HIP_REQUIRE(nb <= 0x7fffffffll, "adam_step: arena too large");
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, params, grads, m, v, P, (float)a,
                        (float)beta1, (float)beta2, (float)epsilon, (float)grad_scale, (float)max_grad_norm, partial,
                        npartial, header);

@@ -73,12 +73,26 @@ __global__ void adv_stats_partial_kernel(const A *__restrict__ advs, const int32
     const int64_t lo = (int64_t)blockIdx.x * per;
     const int64_t hi = lo + per < B ? lo + per : B;
     double s = 0.0, ss = 0.0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const int64_t row = (int64_t)j * B + i;
-        const int64_t smp = idx ? (int64_t)idx[row] : row;
-        const double a = (double)advs[tm_offset(smp, T, E)];
-        s += a;
-        ss += a * a;
+    constexpr int U = 4;      // rows per thread and round: index loads first, then the gathers they address
+    for (int64_t base = lo; base < hi; base += (int64_t)blockDim.x * U) {
+        int64_t smp[U];
+        double a[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + (int64_t)u * blockDim.x + threadIdx.x;
+            const int64_t row = (int64_t)j * B + (i < hi ? i : lo);
+            smp[u] = idx ? (int64_t)idx[row] : row;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) a[u] = (double)advs[tm_offset(smp[u], T, E)];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + (int64_t)u * blockDim.x + threadIdx.x;
+            if (i < hi) {
+                s += a[u];
+                ss += a[u] * a[u];
+            }
+        }
     }
     s = block_sum(s, red);
     ss = block_sum(ss, red);
@@ -88,18 +102,22 @@ __global__ void adv_stats_partial_kernel(const A *__restrict__ advs, const int32
     }
 }
 
+// one wave per minibatch: lanes take chunks lane, lane + 64, ..., then a fixed-order wave sum
 __global__ void adv_stats_final_kernel(const double *__restrict__ partial, int nchunks, int64_t B, int nmb,
                                        double *__restrict__ stats) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nmb) return;
+    const int j = blockIdx.x, lane = threadIdx.x;
     double s = 0.0, ss = 0.0;
-    for (int c = 0; c < nchunks; c++) {
+    for (int c = lane; c < nchunks; c += 64) {
         s += partial[((int64_t)j * nchunks + c) * 2 + 0];
         ss += partial[((int64_t)j * nchunks + c) * 2 + 1];
     }
-    stats[j * 3 + 0] = s;
-    stats[j * 3 + 1] = ss;
-    stats[j * 3 + 2] = (double)B;
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        stats[j * 3 + 0] = s;
+        stats[j * 3 + 1] = ss;
+        stats[j * 3 + 2] = (double)B;
+    }
 }
 
 }  // namespace ppo2hip
@@ -153,6 +171,6 @@ extern "C" int ppo2hip_adv_stats(const void *advs, int adv_f64, const int32_t *i
         hipLaunchKernelGGL(adv_stats_partial_kernel<float>, grid, dim3(256), 0, s, (const float *)advs, idx, B, T, E, partial);
     int rc = check_launch("adv_stats_partial_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(adv_stats_final_kernel, dim3((unsigned)ceil_div(nmb, 64)), dim3(64), 0, s, partial, nchunks, B, nmb, stats);
+    hipLaunchKernelGGL(adv_stats_final_kernel, dim3((unsigned)nmb), dim3(64), 0, s, partial, nchunks, B, nmb, stats);
     return check_launch("adv_stats_final_kernel");
 }

@@ -49,6 +49,21 @@ def dense_flops_per_sample(D, hidden, A, R):
     return tot
 
 
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate
+    rocprofv3 runs of this script), or None when no profile of this workload is on file."""
+    path = os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")
+    try:
+        with open(path) as fh:
+            prof = json.load(fh)
+    except OSError:
+        return None
+    k = prof.get("kernels", {}).get(kernel)
+    if prof.get("workload") != workload or not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
+        return None
+    return k["FETCH_SIZE"] + k["WRITE_SIZE"]
+
+
 def make_rollout(model, cfg, seed, device):
     """Synthetic rollout in HBM: N(0,1) observations and rewards, Bernoulli dones, actions /
     values / neglogpacs from the initial policy (so ratio ~ 1 at the first minibatch)."""
@@ -216,12 +231,15 @@ def main():
                                       "upstream" if cfg["upstream"] else "fork"),
                        "samples_per_step_per_gpu": N, "nbatch_train": B,
                        "parallelism": "env-sharded dp%d, RCCL grad all-reduce (MpiAdam semantics)" % world if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "ppo_grad (minibatch gather+forward+loss+backward, fp32 MFMA GEMMs)",
+            "roofline": {"bound": "mfma", "kernel": "ppo_grad = mlp_fused16_kernel + fused_finalize_kernel (minibatch gather, forward, "
+                                                    "loss, backward and weight gradients on fp32 MFMA)",
                          "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved_tf / MFMA_F32_PEAK_TFLOPS,
+                         "traffic": measured_traffic(args.workload, "ppo2hip::mlp_fused16_kernel<5, true>"),
                          "flops_per_launch": flops_mb, "ms_per_launch": grad_ms},
             "gae_roofline": {"bound": "hbm", "kernel": "gae_kernel", "achieved": gae_gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": gae_gbs / HBM_PEAK_GBS, "bytes_per_launch": gae_bytes,
+                             "traffic": measured_traffic(args.workload, "ppo2hip::gae_kernel<8>"),
                              "ms_per_launch": gae_ms},
             "losses": [float(x) for x in losses],
         }
