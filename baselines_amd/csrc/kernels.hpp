@@ -128,4 +128,19 @@ int lstm_gates_bwd(float *gates, int64_t z_stride, const float *c, const float *
                    int64_t s_stride, const float *dhm_next, float *dcm_carry, const uint8_t *mask_next,
                    int64_t mask_stride, int nenv, int nh, hipStream_t s);
 
+// layer-normalised cell (a2c/utils.py:110-147); see lstm.hip for the buffer meanings
+struct LnLstmParams {
+    const float *gx, *bx, *gh, *bh, *b, *gc, *bc;
+};
+int ln_rows(float *x, int64_t stride, int64_t rows, int n, float *rstd, hipStream_t s);
+int lnlstm_step_fwd(const float *zx, float *zh, int64_t z_stride, float *gates, const LnLstmParams &p, const float *cm,
+                    int64_t s_stride, int nenv, int nh, float *c, float *cn, float *h, float *rstd_h, float *rstd_c,
+                    int64_t r_stride, float *state_out, hipStream_t s);
+int lnlstm_step_bwd(float *gates, const float *zx, const float *zh, float *dzx, float *dzh, int64_t z_stride,
+                    const LnLstmParams &p, const float *cm, const float *cn, const float *dh_head, float *dl,
+                    int64_t s_stride, const float *rstd_x, const float *rstd_h, const float *rstd_c, int64_t r_stride,
+                    const float *dhm_next, float *dcm_carry, const uint8_t *mask_next, int64_t mask_stride, int nenv,
+                    int nh, hipStream_t s);
+int ln_colsum(const float *a, const float *b, int64_t rows, int n, float *out, hipStream_t s);
+
 }  // namespace ppo2hip

@@ -1,4 +1,4 @@
-// Element-wise halves of the LSTM cell of baselines/a2c/utils.py:86-108 (gates in the order
+// Element-wise halves of the LSTM cells of baselines/a2c/utils.py:86-147 (gates in the order
 // i, f, o, u; state [c | h]; c and h zeroed where the done-before-step mask is set).  The
 // matrix products (x wx for all steps at once, h wh per step, and their gradients) run on the
 // MFMA GEMM; these kernels do the masking, the gate non-linearities and their backward.
@@ -64,6 +64,271 @@ __global__ void lstm_gate_bwd_kernel(float *__restrict__ gates, int64_t z_stride
     zr[2 * nh + j] = dh * tc * o * (1.f - o);
     zr[3 * nh + j] = dc * i * (1.f - u * u);
     dcm_carry[cr] = dc * f;
+}
+
+// ---------------------------------------------------------------------------------------
+// Layer-normalised cell (baselines/a2c/utils.py:110-147):
+//   z = LN(x wx; gx, bx) + LN(hm wh; gh, bh) + b,   c = f cm + i u,   h = o tanh(LN(c; gc, bc)),
+//   LN(x; g, b) = (x - mean) / sqrt(var + 1e-5) * g + b over the row, var = mean((x - mean)^2).
+// One 256-thread block per row; thread `tid` owns hidden units tid, tid + 256, ... (up to 4, so
+// nh <= 1024) and for each of them the four gate columns.  Row sums run in double.
+// ---------------------------------------------------------------------------------------
+constexpr int kLnThreads = 256;
+constexpr int kLnUnits = 4;          // hidden units per thread
+constexpr float kLnEps = 1e-5f;
+
+// xhat = (x - mean) * rstd in place, rstd[row] saved; rows are `stride` floats apart
+__global__ __launch_bounds__(kLnThreads) void ln_rows_kernel(float *__restrict__ x, int64_t stride, int n,
+                                                             float *__restrict__ rstd) {
+    __shared__ double red[17];
+    float *row = x + (int64_t)blockIdx.x * stride;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < n; j += kLnThreads) s += (double)row[j];
+    const float mean = (float)(block_sum(s, red) / n);
+    double q = 0.0;
+    for (int j = threadIdx.x; j < n; j += kLnThreads) {
+        const float d = row[j] - mean;
+        q += (double)d * (double)d;
+    }
+    const float r = 1.0f / sqrtf((float)(block_sum(q, red) / n) + kLnEps);
+    for (int j = threadIdx.x; j < n; j += kLnThreads) row[j] = (row[j] - mean) * r;
+    if (threadIdx.x == 0) rstd[blockIdx.x] = r;
+}
+
+struct LnParams {
+    const float *gx, *bx, *gh, *bh, *b, *gc, *bc;
+};
+
+// Step t of every env (block = env).  zx: normalised x wx rows; zh: raw hm wh rows on entry, normalised on
+// exit; gates out (activated i, f, o, u); c, cn (normalised c), h.  Row of env e is e * stride-of-that-array.
+__global__ __launch_bounds__(kLnThreads) void lnlstm_step_fwd_kernel(
+    const float *__restrict__ zx, float *__restrict__ zh, int64_t z_stride, float *__restrict__ gates, LnParams P,
+    const float *__restrict__ cm, int64_t s_stride, int nh, float *__restrict__ c, float *__restrict__ cn,
+    float *__restrict__ h, float *__restrict__ rstd_h, float *__restrict__ rstd_c, int64_t r_stride,
+    float *__restrict__ state_out) {
+    __shared__ double red[17];
+    const int e = blockIdx.x, tid = threadIdx.x, n4 = 4 * nh;
+    const float *zxr = zx + (int64_t)e * z_stride;
+    float *zhr = zh + (int64_t)e * z_stride, *gr = gates + (int64_t)e * z_stride;
+    float v[kLnUnits][4];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kLnUnits; k++) {
+        const int j = tid + k * kLnThreads;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            v[k][g] = j < nh ? zhr[g * nh + j] : 0.f;
+            s += (double)v[k][g];
+        }
+    }
+    const float mean = (float)(block_sum(s, red) / n4);
+    double q = 0.0;
+#pragma unroll
+    for (int k = 0; k < kLnUnits; k++)
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            if (tid + k * kLnThreads < nh) {
+                const float d = v[k][g] - mean;
+                q += (double)d * (double)d;
+            }
+    const float rh = 1.0f / sqrtf((float)(block_sum(q, red) / n4) + kLnEps);
+    float cv[kLnUnits], ov[kLnUnits];
+    double sc = 0.0;
+#pragma unroll
+    for (int k = 0; k < kLnUnits; k++) {
+        const int j = tid + k * kLnThreads;
+        cv[k] = 0.f; ov[k] = 0.f;
+        if (j < nh) {
+            float z[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = g * nh + j;
+                const float xh = (v[k][g] - mean) * rh;
+                zhr[col] = xh;
+                z[g] = (zxr[col] * P.gx[col] + P.bx[col]) + (xh * P.gh[col] + P.bh[col]) + P.b[col];
+            }
+            const float i = sigmoidf(z[0]), f = sigmoidf(z[1]), o = sigmoidf(z[2]), u = tanhf(z[3]);
+            gr[j] = i; gr[nh + j] = f; gr[2 * nh + j] = o; gr[3 * nh + j] = u;
+            cv[k] = f * cm[(int64_t)e * s_stride + j] + i * u;
+            ov[k] = o;
+            sc += (double)cv[k];
+        }
+    }
+    const float mc = (float)(block_sum(sc, red) / nh);
+    double qc = 0.0;
+#pragma unroll
+    for (int k = 0; k < kLnUnits; k++)
+        if (tid + k * kLnThreads < nh) {
+            const float d = cv[k] - mc;
+            qc += (double)d * (double)d;
+        }
+    const float rc = 1.0f / sqrtf((float)(block_sum(qc, red) / nh) + kLnEps);
+#pragma unroll
+    for (int k = 0; k < kLnUnits; k++) {
+        const int j = tid + k * kLnThreads;
+        if (j < nh) {
+            const float ch = (cv[k] - mc) * rc;
+            const float hn = ov[k] * tanhf(ch * P.gc[j] + P.bc[j]);
+            const int64_t sr = (int64_t)e * s_stride + j;
+            c[sr] = cv[k];
+            cn[sr] = ch;
+            h[sr] = hn;
+            if (state_out) {
+                state_out[(int64_t)e * 2 * nh + j] = cv[k];
+                state_out[(int64_t)e * 2 * nh + nh + j] = hn;
+            }
+        }
+    }
+    if (tid == 0) {
+        rstd_h[(int64_t)e * r_stride] = rh;
+        rstd_c[(int64_t)e * r_stride] = rc;
+    }
+}
+
+// Backward of step t (block = env).  gates in: activated i, f, o, u; out: d(loss)/dz.  dl out: d(loss)/d(LN(c)).
+// dzx / dzh out: gradients w.r.t. the raw products x wx / hm wh (through their layer norms).
+__global__ __launch_bounds__(kLnThreads) void lnlstm_step_bwd_kernel(
+    float *__restrict__ gates, const float *__restrict__ zx, const float *__restrict__ zh, float *__restrict__ dzx,
+    float *__restrict__ dzh, int64_t z_stride, LnParams P, const float *__restrict__ cm, const float *__restrict__ cn,
+    const float *__restrict__ dh_head, float *__restrict__ dl, int64_t s_stride, const float *__restrict__ rstd_x,
+    const float *__restrict__ rstd_h, const float *__restrict__ rstd_c, int64_t r_stride,
+    const float *__restrict__ dhm_next, float *__restrict__ dcm_carry, const uint8_t *__restrict__ mask_next,
+    int64_t mask_stride, int nh) {
+    __shared__ double red[17];
+    const int e = blockIdx.x, tid = threadIdx.x, n4 = 4 * nh;
+    float keep = 0.f;   // no later step: no carry
+    if (mask_next) keep = mask_next[(int64_t)e * mask_stride] ? 0.f : 1.f;
+    float *gr = gates + (int64_t)e * z_stride;
+    const float *zxr = zx + (int64_t)e * z_stride, *zhr = zh + (int64_t)e * z_stride;
+    const float rx = rstd_x[(int64_t)e * r_stride], rh = rstd_h[(int64_t)e * r_stride], rc = rstd_c[(int64_t)e * r_stride];
+    float g4[kLnUnits][4], dch[kLnUnits], chv[kLnUnits], dov[kLnUnits];
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kLnUnits; k++) {
+        const int j = tid + k * kLnThreads;
+        dch[k] = 0.f; chv[k] = 0.f; dov[k] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; g++) g4[k][g] = 0.f;
+        if (j < nh) {
+            const int64_t sr = (int64_t)e * s_stride + j, cr = (int64_t)e * nh + j;
+#pragma unroll
+            for (int g = 0; g < 4; g++) g4[k][g] = gr[g * nh + j];
+            const float dh = dh_head[sr] + (mask_next ? dhm_next[cr] * keep : 0.f);
+            const float ch = cn[sr];
+            const float tl = tanhf(ch * P.gc[j] + P.bc[j]);
+            dov[k] = dh * tl;
+            const float dlnc = dh * g4[k][2] * (1.f - tl * tl);
+            dl[sr] = dlnc;
+            chv[k] = ch;
+            dch[k] = dlnc * P.gc[j];
+            s1 += (double)dch[k];
+            s2 += (double)dch[k] * (double)ch;
+        }
+    }
+    const float m1 = (float)(block_sum(s1, red) / nh), m2 = (float)(block_sum(s2, red) / nh);
+    float dz[kLnUnits][4];
+    double ax1 = 0.0, ax2 = 0.0, ah1 = 0.0, ah2 = 0.0;
+    float xx[kLnUnits][4], xh[kLnUnits][4];
+#pragma unroll
+    for (int k = 0; k < kLnUnits; k++) {
+        const int j = tid + k * kLnThreads;
+#pragma unroll
+        for (int g = 0; g < 4; g++) { dz[k][g] = 0.f; xx[k][g] = 0.f; xh[k][g] = 0.f; }
+        if (j < nh) {
+            const int64_t sr = (int64_t)e * s_stride + j, cr = (int64_t)e * nh + j;
+            const float i = g4[k][0], f = g4[k][1], o = g4[k][2], u = g4[k][3];
+            const float dc = (mask_next ? dcm_carry[cr] * keep : 0.f) + rc * (dch[k] - m1 - chv[k] * m2);
+            dz[k][0] = dc * u * i * (1.f - i);
+            dz[k][1] = dc * cm[sr] * f * (1.f - f);
+            dz[k][2] = dov[k] * o * (1.f - o);
+            dz[k][3] = dc * i * (1.f - u * u);
+            dcm_carry[cr] = dc * f;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = g * nh + j;
+                gr[col] = dz[k][g];
+                xx[k][g] = zxr[col];
+                xh[k][g] = zhr[col];
+                const float dx = dz[k][g] * P.gx[col], dhh = dz[k][g] * P.gh[col];
+                ax1 += (double)dx; ax2 += (double)dx * (double)xx[k][g];
+                ah1 += (double)dhh; ah2 += (double)dhh * (double)xh[k][g];
+            }
+        }
+    }
+    const float mx1 = (float)(block_sum(ax1, red) / n4), mx2 = (float)(block_sum(ax2, red) / n4);
+    const float mh1 = (float)(block_sum(ah1, red) / n4), mh2 = (float)(block_sum(ah2, red) / n4);
+    float *dxr = dzx + (int64_t)e * z_stride, *dhr = dzh + (int64_t)e * z_stride;
+#pragma unroll
+    for (int k = 0; k < kLnUnits; k++) {
+        const int j = tid + k * kLnThreads;
+        if (j < nh) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int col = g * nh + j;
+                dxr[col] = rx * (dz[k][g] * P.gx[col] - mx1 - xx[k][g] * mx2);
+                dhr[col] = rh * (dz[k][g] * P.gh[col] - mh1 - xh[k][g] * mh2);
+            }
+        }
+    }
+}
+
+// out_prod[j] = sum_r a[r, j] * b[r, j] (b null: plain column sums) over `rows` rows, fixed order;
+// the gain / bias gradients of the layer norms.  One thread per column, rows read in batches.
+__global__ void ln_colsum_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t rows, int n,
+                                 float *__restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    constexpr int U = 8;
+    for (int64_t r0 = 0; r0 < rows; r0 += U) {
+        float x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t r = r0 + u < rows ? r0 + u : rows - 1;
+            x[u] = a[r * n + j];
+            y[u] = b ? b[r * n + j] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (r0 + u < rows) s += (double)x[u] * (double)y[u];
+    }
+    out[j] = (float)s;
+}
+
+int ln_rows(float *x, int64_t stride, int64_t rows, int n, float *rstd, hipStream_t s) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned)rows), dim3(kLnThreads), 0, s, x, stride, n, rstd);
+    return check_launch("ln_rows_kernel");
+}
+
+int lnlstm_step_fwd(const float *zx, float *zh, int64_t z_stride, float *gates, const LnLstmParams &p, const float *cm,
+                    int64_t s_stride, int nenv, int nh, float *c, float *cn, float *h, float *rstd_h, float *rstd_c,
+                    int64_t r_stride, float *state_out, hipStream_t s) {
+    if (nh > kLnThreads * kLnUnits) {
+        set_error("lnlstm: nlstm=%d above the %d the cell kernels cover", nh, kLnThreads * kLnUnits);
+        return PPO2HIP_EUNSUPPORTED;
+    }
+    LnParams P{p.gx, p.bx, p.gh, p.bh, p.b, p.gc, p.bc};
+    hipLaunchKernelGGL(lnlstm_step_fwd_kernel, dim3(nenv), dim3(kLnThreads), 0, s, zx, zh, z_stride, gates, P, cm, s_stride,
+                       nh, c, cn, h, rstd_h, rstd_c, r_stride, state_out);
+    return check_launch("lnlstm_step_fwd_kernel");
+}
+
+int lnlstm_step_bwd(float *gates, const float *zx, const float *zh, float *dzx, float *dzh, int64_t z_stride,
+                    const LnLstmParams &p, const float *cm, const float *cn, const float *dh_head, float *dl,
+                    int64_t s_stride, const float *rstd_x, const float *rstd_h, const float *rstd_c, int64_t r_stride,
+                    const float *dhm_next, float *dcm_carry, const uint8_t *mask_next, int64_t mask_stride, int nenv,
+                    int nh, hipStream_t s) {
+    LnParams P{p.gx, p.bx, p.gh, p.bh, p.b, p.gc, p.bc};
+    hipLaunchKernelGGL(lnlstm_step_bwd_kernel, dim3(nenv), dim3(kLnThreads), 0, s, gates, zx, zh, dzx, dzh, z_stride, P, cm,
+                       cn, dh_head, dl, s_stride, rstd_x, rstd_h, rstd_c, r_stride, dhm_next, dcm_carry, mask_next,
+                       mask_stride, nh);
+    return check_launch("lnlstm_step_bwd_kernel");
+}
+
+int ln_colsum(const float *a, const float *b, int64_t rows, int n, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(ln_colsum_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64), 0, s, a, b, rows, n, out);
+    return check_launch("ln_colsum_kernel");
 }
 
 int lstm_mask(const float *c_prev, const float *h_prev, int64_t prev_stride, const uint8_t *masks, int64_t mask_stride,

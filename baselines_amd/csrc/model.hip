@@ -254,11 +254,12 @@ static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
 }
 
 // ---------------------------------------------------------------------------------------
-// nature_cnn (+ LSTM) policies: baselines/ppo2/policies.py:6-130, baselines/a2c/utils.py:86-108
+// nature_cnn (+ LSTM / layer-normalised LSTM) policies: baselines/ppo2/policies.py:6-130, baselines/a2c/utils.py:86-147
 // ---------------------------------------------------------------------------------------
 struct CnnDims {
     int H, W, C, h1, w1, h2, w2, h3, w3, flat, feat, nh, nact;
-    bool lstm;
+    bool lstm;   // recurrent (either cell)
+    bool ln;     // layer-normalised cell
 };
 static CnnDims cnn_dims(const ppo2hip_policy_desc &d) {
     CnnDims c;
@@ -267,7 +268,8 @@ static CnnDims cnn_dims(const ppo2hip_policy_desc &d) {
     c.h2 = conv_out(c.h1, 4, 2); c.w2 = conv_out(c.w1, 4, 2);
     c.h3 = conv_out(c.h2, 3, 1); c.w3 = conv_out(c.w2, 3, 1);
     c.flat = c.h3 * c.w3 * 64;
-    c.lstm = d.kind == PPO2HIP_POLICY_CNN_LSTM;
+    c.lstm = d.kind == PPO2HIP_POLICY_CNN_LSTM || d.kind == PPO2HIP_POLICY_CNN_LNLSTM;
+    c.ln = d.kind == PPO2HIP_POLICY_CNN_LNLSTM;
     c.nh = d.nlstm;
     c.feat = c.lstm ? d.nlstm : 512;
     c.nact = d.ac_dim;
@@ -283,7 +285,9 @@ struct CnnBuf {
     float *RET, *OLDV, *NLP, *ADV;
     float *Y1, *Y2, *Y3, *F, *PI, *VF;
     float *Z, *HM, *CM, *C, *Hs, *S0;          // LSTM: gates [B,4nh], masked prev states, states, gathered initial state
+    float *ZX, *ZH, *CN, *RX, *RH, *RC;        // layer-normalised cell: normalised x wx / hm wh / c rows and their 1/std
     float *dPI, *dVF, *dF, *dY3, *dY2, *dY1, *DH, *dhm, *dcm;
+    float *DZX, *DZH, *DL;                     // ... gradients w.r.t. the raw products and w.r.t. LN(c)
     float *slabs;
     int max_slabs;
     double *loss_partial;
@@ -300,6 +304,10 @@ static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver 
         w.HM = c.take<float>(B * k.nh); w.CM = c.take<float>(B * k.nh);
         w.C = c.take<float>(B * k.nh); w.Hs = c.take<float>(B * k.nh);
         w.S0 = c.take<float>((int64_t)nenv * 2 * k.nh);
+        if (k.ln) {
+            w.ZX = c.take<float>(B * 4 * k.nh); w.ZH = c.take<float>(B * 4 * k.nh); w.CN = c.take<float>(B * k.nh);
+            w.RX = c.take<float>(B); w.RH = c.take<float>(B); w.RC = c.take<float>(B);
+        }
     }
     if (!grad) return;
     w.X = c.take<uint8_t>(B * k.H * k.W * k.C);
@@ -315,6 +323,9 @@ static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver 
     if (k.lstm) {
         w.DH = c.take<float>(B * k.nh);
         w.dhm = c.take<float>((int64_t)nenv * k.nh); w.dcm = c.take<float>((int64_t)nenv * k.nh);
+        if (k.ln) {
+            w.DZX = c.take<float>(B * 4 * k.nh); w.DZH = c.take<float>(B * 4 * k.nh); w.DL = c.take<float>(B * k.nh);
+        }
     }
     // weight-gradient slabs: the largest layer decides
     int64_t se = 0;
@@ -354,6 +365,25 @@ static int lstm_forward_all(const ppo2hip_policy_desc &d, const Layout &L, const
     const int nh = d.nlstm;
     const int64_t B = (int64_t)nenv * T;
     int rc;
+    if (d.kind == PPO2HIP_POLICY_CNN_LNLSTM) {
+        const LnLstmParams P{p + L.off("lstm1/gx"), p + L.off("lstm1/bx"), p + L.off("lstm1/gh"), p + L.off("lstm1/bh"),
+                             p + L.off("lstm1/b"), p + L.off("lstm1/gc"), p + L.off("lstm1/bc")};
+        // x wx for every row at once, normalised in place
+        if ((rc = fc_forward(w.F, 512, p + L.off("lstm1/wx"), nullptr, w.ZX, 4 * nh, (int)B, 4 * nh, 512, ACT_NONE, false, s))) return rc;
+        if ((rc = ln_rows(w.ZX, 4 * nh, B, 4 * nh, w.RX, s))) return rc;
+        const float *wh = p + L.off("lstm1/wh");
+        for (int t = 0; t < T; t++) {
+            const float *cprev = t == 0 ? w.S0 : w.C + (int64_t)(t - 1) * nh;
+            const float *hprev = t == 0 ? w.S0 + nh : w.Hs + (int64_t)(t - 1) * nh;
+            const int64_t pstride = t == 0 ? 2 * nh : (int64_t)T * nh;
+            if ((rc = lstm_mask(cprev, hprev, pstride, masks + t, T, nenv, nh, w.CM + (int64_t)t * nh, w.HM + (int64_t)t * nh, (int64_t)T * nh, s))) return rc;
+            if ((rc = fc_forward(w.HM + (int64_t)t * nh, T * nh, wh, nullptr, w.ZH + (int64_t)t * 4 * nh, T * 4 * nh, nenv, 4 * nh, nh, ACT_NONE, false, s))) return rc;
+            if ((rc = lnlstm_step_fwd(w.ZX + (int64_t)t * 4 * nh, w.ZH + (int64_t)t * 4 * nh, (int64_t)T * 4 * nh, w.Z + (int64_t)t * 4 * nh, P,
+                                      w.CM + (int64_t)t * nh, (int64_t)T * nh, nenv, nh, w.C + (int64_t)t * nh, w.CN + (int64_t)t * nh,
+                                      w.Hs + (int64_t)t * nh, w.RH + t, w.RC + t, T, t == T - 1 ? state_out : nullptr, s))) return rc;
+        }
+        return 0;
+    }
     // x wx + b for every row at once
     if ((rc = fc_forward(w.F, 512, p + L.off("lstm1/wx"), p + L.off("lstm1/b"), w.Z, 4 * nh, (int)B, 4 * nh, 512, ACT_NONE, false, s))) return rc;
     const float *wh = p + L.off("lstm1/wh");
@@ -438,6 +468,31 @@ static int cnn_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
         if ((rc = fc_dgrad(w.dPI, k.nact, p + L.off("pi/w"), nh, k.nact, nullptr, 0, ACT_NONE, w.DH, nh, (int)B, false, s))) return rc;
         if ((rc = fc_dgrad(w.dVF, 1, p + L.off("v/w"), nh, 1, nullptr, 0, ACT_NONE, w.DH, nh, (int)B, true, s))) return rc;
         const float *wh = p + L.off("lstm1/wh");
+        if (k.ln) {
+            const LnLstmParams P{p + L.off("lstm1/gx"), p + L.off("lstm1/bx"), p + L.off("lstm1/gh"), p + L.off("lstm1/bh"),
+                                 p + L.off("lstm1/b"), p + L.off("lstm1/gc"), p + L.off("lstm1/bc")};
+            for (int t = T - 1; t >= 0; t--) {
+                const uint8_t *mnext = t == T - 1 ? nullptr : w.MASK + (t + 1);
+                const int64_t o4 = (int64_t)t * 4 * nh, o1 = (int64_t)t * nh;
+                if ((rc = lnlstm_step_bwd(w.Z + o4, w.ZX + o4, w.ZH + o4, w.DZX + o4, w.DZH + o4, (int64_t)T * 4 * nh, P, w.CM + o1,
+                                          w.CN + o1, w.DH + o1, w.DL + o1, (int64_t)T * nh, w.RX + t, w.RH + t, w.RC + t, T, w.dhm,
+                                          w.dcm, mnext, T, nenv, nh, s))) return rc;
+                // dhm = (gradient w.r.t. hm wh) wh^T
+                if (t > 0 && (rc = fc_dgrad(w.DZH + o4, T * 4 * nh, wh, nh, 4 * nh, nullptr, 0, ACT_NONE, w.dhm, nh, nenv, false, s))) return rc;
+            }
+            // Z holds dz, ZX / ZH the normalised products, DZX / DZH the gradients of the raw products.  The
+            // products' appended ones-rows land on gx / gh, which the gain gradients then overwrite.
+            if ((rc = wgrad_into(w.F, 512, w.DZX, 4 * nh, B, 512, 4 * nh, w.slabs, w.max_slabs, grads + L.off("lstm1/wx"), s))) return rc;
+            if ((rc = wgrad_into(w.HM, nh, w.DZH, 4 * nh, B, nh, 4 * nh, w.slabs, w.max_slabs, grads + L.off("lstm1/wh"), s))) return rc;
+            if ((rc = ln_colsum(w.Z, w.ZX, B, 4 * nh, grads + L.off("lstm1/gx"), s))) return rc;
+            if ((rc = ln_colsum(w.Z, w.ZH, B, 4 * nh, grads + L.off("lstm1/gh"), s))) return rc;
+            if ((rc = ln_colsum(w.Z, nullptr, B, 4 * nh, grads + L.off("lstm1/bx"), s))) return rc;   // bx, bh and b all add to z
+            if ((rc = ln_colsum(w.Z, nullptr, B, 4 * nh, grads + L.off("lstm1/bh"), s))) return rc;
+            if ((rc = ln_colsum(w.Z, nullptr, B, 4 * nh, grads + L.off("lstm1/b"), s))) return rc;
+            if ((rc = ln_colsum(w.DL, w.CN, B, nh, grads + L.off("lstm1/gc"), s))) return rc;
+            if ((rc = ln_colsum(w.DL, nullptr, B, nh, grads + L.off("lstm1/bc"), s))) return rc;
+            if ((rc = fc_dgrad(w.DZX, 4 * nh, p + L.off("lstm1/wx"), 512, 4 * nh, w.F, 512, ACT_RELU, w.dF, 512, (int)B, false, s))) return rc;
+        } else {
         for (int t = T - 1; t >= 0; t--) {
             const uint8_t *mnext = t == T - 1 ? nullptr : w.MASK + (t + 1);
             if ((rc = lstm_gates_bwd(w.Z + (int64_t)t * 4 * nh, (int64_t)T * 4 * nh, w.C + (int64_t)t * nh, w.CM + (int64_t)t * nh,
@@ -450,6 +505,7 @@ static int cnn_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
         if ((rc = wgrad_into(w.F, 512, w.Z, 4 * nh, B, 512, 4 * nh, w.slabs, w.max_slabs, grads + L.off("lstm1/wx"), s))) return rc;
         if ((rc = wgrad_into(w.HM, nh, w.Z, 4 * nh, B, nh, 4 * nh, w.slabs, w.max_slabs, grads + L.off("lstm1/wh"), s))) return rc;
         if ((rc = fc_dgrad(w.Z, 4 * nh, p + L.off("lstm1/wx"), 512, 4 * nh, w.F, 512, ACT_RELU, w.dF, 512, (int)B, false, s))) return rc;
+        }
     }
     // fc1
     if ((rc = wgrad_into(w.Y3, k.flat, w.dF, 512, B, k.flat, 512, w.slabs, w.max_slabs, grads + L.off("fc1/w"), s))) return rc;
@@ -515,7 +571,9 @@ extern "C" int ppo2hip_param_layout(const ppo2hip_policy_desc *desc, int max_var
     return n;
 }
 
-static bool cnn_kind(const ppo2hip_policy_desc &d) { return d.kind == PPO2HIP_POLICY_CNN || d.kind == PPO2HIP_POLICY_CNN_LSTM; }
+static bool cnn_kind(const ppo2hip_policy_desc &d) {
+    return d.kind == PPO2HIP_POLICY_CNN || d.kind == PPO2HIP_POLICY_CNN_LSTM || d.kind == PPO2HIP_POLICY_CNN_LNLSTM;
+}
 
 extern "C" size_t ppo2hip_forward_workspace_bytes(const ppo2hip_policy_desc *desc, int64_t B) {
     if (!desc || B < 0) return 0;
@@ -570,7 +628,7 @@ extern "C" int ppo2hip_policy_forward(const ppo2hip_policy_desc *desc, const flo
     if (cnn_kind(*desc))
         return cnn_policy_forward(*desc, L, params, obs, B, masks, states_in, pi, vf, states_out, workspace,
                                   workspace_bytes, s);
-    set_error("policy_forward: policy kind %d (layer-normalised LSTM) is not built", desc->kind);
+    set_error("policy_forward: unknown policy kind %d", desc->kind);
     return PPO2HIP_EUNSUPPORTED;
 }
 
@@ -608,7 +666,7 @@ extern "C" int ppo2hip_ppo_grad(const ppo2hip_policy_desc *desc, const ppo2hip_l
     if (cnn_kind(*desc))
         return cnn_grad(*desc, *loss, L, params, *rollout, idx, B, mb_envs, nsteps_mb, stats, cliprange, inv_count, grads,
                         losses, workspace, workspace_bytes, s);
-    set_error("ppo_grad: policy kind %d (layer-normalised LSTM) is not built", desc->kind);
+    set_error("ppo_grad: unknown policy kind %d", desc->kind);
     return PPO2HIP_EUNSUPPORTED;
 }
 

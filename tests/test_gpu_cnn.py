@@ -75,16 +75,23 @@ def test_cnn_policy_grad(hip, hwc, nact, T, E, B):
     np.testing.assert_allclose(vf.cpu().numpy(), o_vf.numpy(), rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("cell", ["lstm", "lnlstm"])
 @pytest.mark.parametrize("hwc,nact,T,E,nenv_mb,nlstm", [((36, 36, 2), 4, 6, 6, 3, 32), ((44, 52, 4), 5, 5, 8, 4, 64),
                                                         ((84, 84, 4), 6, 4, 4, 2, 256)])
-def test_cnn_lstm_policy_grad(hip, hwc, nact, T, E, nenv_mb, nlstm):
-    """Env-sequence minibatch (baselines/ppo2/ppo2.py:124-136): whole env rows, masks reset the state."""
+def test_cnn_lstm_policy_grad(hip, hwc, nact, T, E, nenv_mb, nlstm, cell):
+    """Env-sequence minibatch (baselines/ppo2/ppo2.py:124-136): whole env rows, masks reset the state;
+    plain cell (a2c/utils.py:86-108) and layer-normalised cell (:110-147, gains and biases perturbed
+    away from their 1 / 0 initial values so that every term of their gradients is exercised)."""
     from baselines_amd import _lib
-    spec = hip.PolicySpec(_lib.POLICY_CNN_LSTM, _lib.DIST_CATEGORICAL, nact, 1, ob_hwc=hwc, nlstm=nlstm)
-    shapes = tfgraph.cnn_param_shapes(hwc[2], nact, "lstm", nlstm, flat=util.cnn_flat(hwc[0], hwc[1]))
+    kind = _lib.POLICY_CNN_LSTM if cell == "lstm" else _lib.POLICY_CNN_LNLSTM
+    spec = hip.PolicySpec(kind, _lib.DIST_CATEGORICAL, nact, 1, ob_hwc=hwc, nlstm=nlstm)
+    shapes = tfgraph.cnn_param_shapes(hwc[2], nact, cell, nlstm, flat=util.cnn_flat(hwc[0], hwc[1]))
     params = util.make_params(shapes, 7, pi_scale=0.5, jitter=0.002)
     rng = np.random.RandomState(8)
-    ro = util.synthetic_cnn_rollout(rng, T, E, hwc, nact, params, kind="lstm", nlstm=nlstm)
+    if cell == "lnlstm":
+        for name in ("lstm1/gx", "lstm1/bx", "lstm1/gh", "lstm1/bh", "lstm1/b", "lstm1/gc", "lstm1/bc"):
+            params[name] = (params[name] + 0.1 * rng.randn(*params[name].shape)).astype(np.float32)
+    ro = util.synthetic_cnn_rollout(rng, T, E, hwc, nact, params, kind=cell, nlstm=nlstm)
     ro["states"] = (0.3 * rng.randn(E, 2 * nlstm)).astype(np.float32)     # non-trivial initial states
     _, rets = scan.gae(ro["rewards"], ro["values"], ro["dones"], ro["last_values"], ro["last_dones"], 0.99, 0.95)
     advs_tm = (rets - ro["values"])[:, :, 0]
@@ -92,7 +99,7 @@ def test_cnn_lstm_policy_grad(hip, hwc, nact, T, E, nenv_mb, nlstm):
     flat = (envs[:, None] * T + np.arange(T)[None, :]).ravel().astype(np.int32)
     B = flat.size
     f = lambda a: scan.sf01(a)[flat]
-    oracle = tfgraph.TrainOracle(params, "lstm", "categorical", tfgraph.LossCfg(0.01, 0.5, 0.5, True))
+    oracle = tfgraph.TrainOracle(params, cell, "categorical", tfgraph.LossCfg(0.01, 0.5, 0.5, True))
     o_losses = oracle.train(2.5e-4, 0.1, f(ro["obs"]), f(rets), f(ro["dones"]), f(ro["actions"]), f(ro["values"]),
                             f(advs_tm), f(ro["neglogpacs"]), states=ro["states"][envs])
     theta = dev(util.flatten_params(params, spec))
@@ -112,16 +119,16 @@ def test_cnn_lstm_policy_grad(hip, hwc, nact, T, E, nenv_mb, nlstm):
     pi, vf, snew = hip.policy_forward(spec, th, dev(ro["obs"][0]), fws, masks=dev(ro["dones"][0]), states=dev(ro["states"]))
     p = tfgraph.to_torch(params, torch.float64, requires_grad=False)
     o_pi, o_vf, o_s = tfgraph.cnn_lstm_forward(p, torch.as_tensor(ro["obs"][0]), torch.as_tensor(ro["dones"][0].astype(np.float64)),
-                                               torch.as_tensor(ro["states"]).double(), E, 1)
+                                               torch.as_tensor(ro["states"]).double(), E, 1, layer_norm=(cell == "lnlstm"))
     np.testing.assert_allclose(pi.cpu().numpy(), o_pi.numpy(), rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(snew.cpu().numpy(), o_s.numpy(), rtol=2e-5, atol=2e-6)
 
 
-def test_lnlstm_is_refused_not_faked(hip):
+def test_lnlstm_width_limit_is_an_error_not_a_fallback(hip):
+    """The layer-normalised cell kernels cover nlstm <= 1024; beyond that the library says so."""
     from baselines_amd import _lib
-    spec = hip.PolicySpec(_lib.POLICY_CNN_LNLSTM, _lib.DIST_CATEGORICAL, 4, 1, ob_hwc=(36, 36, 2), nlstm=32)
-    assert spec.forward_workspace_bytes(4) == 0
-    with pytest.raises((ValueError, _lib.Ppo2HipError)):
-        hip.policy_forward(spec, torch.zeros(spec.nparams, device="cuda"), torch.zeros((4, 36, 36, 2), dtype=torch.uint8, device="cuda"),
-                           torch.empty(256, dtype=torch.uint8, device="cuda"), masks=torch.zeros(4, dtype=torch.uint8, device="cuda"),
-                           states=torch.zeros((4, 64), device="cuda"))
+    spec = hip.PolicySpec(_lib.POLICY_CNN_LNLSTM, _lib.DIST_CATEGORICAL, 4, 1, ob_hwc=(36, 36, 2), nlstm=1100)
+    fws = torch.empty(spec.forward_workspace_bytes(2), dtype=torch.uint8, device="cuda")
+    with pytest.raises(_lib.Ppo2HipError):
+        hip.policy_forward(spec, torch.zeros(spec.nparams, device="cuda"), torch.zeros((2, 36, 36, 2), dtype=torch.uint8, device="cuda"),
+                           fws, masks=torch.zeros(2, dtype=torch.uint8, device="cuda"), states=torch.zeros((2, 2200), device="cuda"))
