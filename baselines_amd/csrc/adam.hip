@@ -24,7 +24,7 @@ __global__ void sumsq_partial_kernel(const float *__restrict__ g, int64_t P, flo
 // npartial == 0 with clipping on: the arena is small, so every block sums the squares of the
 // WHOLE gradient itself (same order in every block, hence the same norm) and no separate
 // norm launch is needed.  Loads are issued in batches so that a batch costs one round trip.
-__global__ void adam_kernel(float *__restrict__ theta, const float *__restrict__ g, float *__restrict__ m,
+__global__ __launch_bounds__(1024) void adam_kernel(float *__restrict__ theta, const float *__restrict__ g, float *__restrict__ m,
                             float *__restrict__ v, int64_t P, float a, float beta1, float beta2, float eps,
                             float gscale, float max_norm, const double *__restrict__ partial, int npartial,
                             float *__restrict__ header) {
@@ -46,7 +46,7 @@ __global__ void adam_kernel(float *__restrict__ theta, const float *__restrict__
     }
     double own = 0.0;
     if (max_norm > 0.f && npartial == 0) {
-        constexpr int W = 8;
+        constexpr int W = 16;
         for (int64_t base = 0; base < P; base += (int64_t)nt * W) {
             float x[W];
 #pragma unroll
@@ -114,9 +114,11 @@ extern "C" int ppo2hip_adam_step(float *params, const float *grads, float *m, fl
         if (rc) return rc;
     }
     const double a = lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t));
-    const int64_t nb = ceil_div(P, 1024);      // 256 threads x 4 elements per block
+    // small arenas (norm summed inside every block): 1024 threads, so that the norm pass is one batch of loads
+    const int threads = npartial == 0 && max_grad_norm > 0.0 ? 1024 : 256;
+    const int64_t nb = ceil_div(P, (int64_t)threads * 4);      // 4 elements per thread
     PPO2HIP_REQUIRE(nb <= 0x7fffffffll, "adam_step: arena too large");
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, params, grads, m, v, P, (float)a,
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(threads), 0, s, params, grads, m, v, P, (float)a,
                        (float)beta1, (float)beta2, (float)epsilon, (float)grad_scale, (float)max_grad_norm, partial,
                        npartial, header);
     return check_launch("adam_kernel");

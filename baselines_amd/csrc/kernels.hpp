@@ -88,22 +88,9 @@ struct FusedImage {
     int s_w1, s_w2, s_wh, s_bh, head_cols;
     int s_logstd;   // where the image holds the summed logstd gradient, or -1: it is in the loss partial rows
 };
-// Clip + Adam step that the last block of the finalize launch applies to the whole arena (single
-// process, arenas of at most kAdamFuseMax parameters); a = lr * sqrt(1 - beta2^t) / (1 - beta1^t).
-struct AdamFuse {
-    float *theta, *m, *v;
-    int64_t P;
-    float a, beta1, beta2, eps, max_norm;
-    float *header;    // [0] global norm, [1] applied scale (the adam scratch header)
-};
-constexpr int64_t kAdamFuseMax = 65536;
-constexpr int kFinalizeMaxBlocks = 2048;                      // partial-norm slots after the ticket
-constexpr size_t kTicketBytes = 256 + kFinalizeMaxBlocks * sizeof(double);
-// ticket: kTicketBytes of device scratch that starts with the counter the blocks draw from, zero on entry
-// (the gradient kernel clears it); used with adam
 int fused_finalize(const FusedImage &im, const float *slabs, int nslabs, const double *lpart, int nloss_rows,
                    const ppo2hip_policy_desc &d, const FusedOffsets &fo, double inv_count, float *grads, float *losses,
-                   const AdamFuse *adam, unsigned *ticket, hipStream_t s);
+                   hipStream_t s);
 bool mlp_fused16_supported(const ppo2hip_policy_desc &d);
 // every rollout array and the index list stay under 4 GB (the kernel addresses them with 32-bit byte offsets)
 bool mlp_fused16_fits(const ppo2hip_policy_desc &d, const ppo2hip_rollout &ro, int64_t B);
@@ -111,7 +98,7 @@ size_t mlp_fused16_workspace_bytes();
 int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params,
                      const FusedOffsets &fo, const ppo2hip_rollout &ro, const int32_t *idx, int64_t B,
                      const double *stats, float cliprange, double inv_count, float *grads, float *losses, void *ws,
-                     size_t ws_bytes, const AdamFuse *adam, hipStream_t s);
+                     size_t ws_bytes, hipStream_t s);
 bool mlp_fused_supported(const ppo2hip_policy_desc &d);
 size_t mlp_fused_workspace_bytes();
 int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params,

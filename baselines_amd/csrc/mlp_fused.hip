@@ -540,61 +540,12 @@ struct FinalizeArgs {
     int nloss_rows, A_gaussian;
     double inv_count;
     float *losses, *dlogstd;
-    unsigned *ticket;     // blocks-finished counter (zero on entry) when the last block runs the optimiser, else null
-    double *sumsq;        // per-block partial squared norms of the gradient (beside the ticket)
-    AdamFuse adam;
 };
 
 constexpr int kFinGroups = 16;   // slab groups per block: 1024 threads, every lane a handful of independent loads
 
-// Clip + Adam over the whole arena by one block (the update of baselines/common/mpi_adam.py:30-35
-// under tf.clip_by_global_norm, as adam_kernel applies it).  The squared norm arrives as one
-// partial sum per gradient-producing block, added here in block order.
-__device__ void adam_by_one_block(const AdamFuse &a, const float *__restrict__ g, const double *__restrict__ sumsq,
-                                  int nparts, double *red) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    float scale = 1.f;
-    if (a.max_norm > 0.f) {
-        double own = 0.0;
-        for (int i = tid; i < nparts; i += nt) own += sumsq[i];
-        own = block_sum(own, red);
-        const float norm = (float)sqrt(own);
-        scale = a.max_norm / fmaxf(norm, a.max_norm);
-        if (tid == 0) a.header[0] = norm;
-    }
-    if (tid == 0) a.header[1] = scale;
-    const float omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
-    constexpr int U = 4;    // elements per thread and round: all their loads are in flight together
-    for (int64_t base = 0; base < a.P; base += (int64_t)nt * U) {
-        float gi[U], mi[U], vi[U], th[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int64_t i = base + (int64_t)u * nt + tid;
-            const bool ok = i < a.P;
-            gi[u] = ok ? g[i] : 0.f;
-            mi[u] = ok ? a.m[i] : 0.f;
-            vi[u] = ok ? a.v[i] : 0.f;
-            th[u] = ok ? a.theta[i] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int64_t i = base + (int64_t)u * nt + tid;
-            if (i < a.P) {
-                const float gs = gi[u] * scale;
-                const float m1 = a.beta1 * mi[u] + omb1 * gs;
-                const float v1 = a.beta2 * vi[u] + omb2 * (gs * gs);
-                a.m[i] = m1;
-                a.v[i] = v1;
-                a.theta[i] = th[u] + (-a.a) * m1 / (sqrtf(v1) + a.eps);
-            }
-        }
-    }
-}
-
 __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(FinalizeArgs f) {
     __shared__ float part[kFinGroups][64];
-    __shared__ double red[17];
-    __shared__ unsigned last_s;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int b = blockIdx.x;
     if (b < f.nseg_blocks + f.nhead_blocks) {
@@ -638,15 +589,11 @@ __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(Finaliz
             for (int z = grp; z < f.nslabs; z += kFinGroups) s += p[(int64_t)z * f.slab_elems];
         part[grp][lane] = s;
         __syncthreads();
-        if (grp == 0) {
+        if (grp == 0 && out) {
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < kFinGroups; q++) t += part[q][lane];
-            if (out) *out = t;
-            if (f.ticket) {     // this block's share of the squared gradient norm (lanes without an output hold 0)
-                const double sq = wave_sum((double)t * (double)t);
-                if (lane == 0) f.sumsq[b] = sq;
-            }
+            *out = t;
         }
     } else {
         // loss scalars (+ the logstd gradient when it travels in the loss partial rows): one wave per output
@@ -662,29 +609,11 @@ __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(Finaliz
             }
         }
     }
-    if (!f.ticket) return;
-    // The block that finishes last applies the optimiser: every block publishes its part of the gradient
-    // (stores drained, device-scope release, then the ticket), the last one acquires before reading.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = (t == gridDim.x - 1) ? 1u : 0u;
-        if (last_s) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-    __syncthreads();
-    if (!last_s) return;
-    adam_by_one_block(f.adam, f.grads, f.sumsq, f.nseg_blocks + f.nhead_blocks, red);
 }
 
 int fused_finalize(const FusedImage &im, const float *slabs, int nslabs, const double *lpart, int nloss_rows,
                    const ppo2hip_policy_desc &d, const FusedOffsets &fo, double inv_count, float *grads, float *losses,
-                   const AdamFuse *adam, unsigned *ticket, hipStream_t s) {
+                   hipStream_t s) {
     const int H1 = d.hidden1, H2 = d.hidden2, D = d.ob_dim, A = d.ac_dim, R = d.nvalue;
     FinalizeArgs fa;
     fa.t.n = 0;
@@ -707,14 +636,6 @@ int fused_finalize(const FusedImage &im, const float *slabs, int nslabs, const d
     fa.a_dst = fo.a_wh; fa.v_dst = fo.v_wh;
     fa.grads = grads; fa.loss_partial = lpart; fa.nloss_rows = nloss_rows; fa.A_gaussian = gauss ? A : 0;
     fa.inv_count = inv_count; fa.losses = losses; fa.dlogstd = gauss ? grads + fo.logstd : nullptr;
-    fa.ticket = adam ? ticket : nullptr;
-    fa.sumsq = adam ? (double *)(ticket + 64) : nullptr;      // 256 bytes on from the ticket
-    if (adam && fa.nseg_blocks + fa.nhead_blocks > kFinalizeMaxBlocks) {
-        set_error("fused_finalize: %d gradient blocks exceed the optimiser scratch", fa.nseg_blocks + fa.nhead_blocks);
-        return PPO2HIP_EINVAL;
-    }
-    if (adam) fa.adam = *adam;
-    else fa.adam = AdamFuse{};
     hipLaunchKernelGGL(fused_finalize_kernel, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(64 * kFinGroups), 0, s, fa);
     return check_launch("fused_finalize_kernel");
 }
@@ -766,7 +687,7 @@ int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, co
 
     FusedImage im;
     im.slab_elems = L::SLAB; im.s_w1 = L::S_W1; im.s_w2 = L::S_W2; im.s_wh = L::S_WH; im.s_bh = L::S_BH; im.head_cols = 32; im.s_logstd = -1;
-    return fused_finalize(im, slabs, grid / 2, lpart, grid, d, fo, inv_count, grads, losses, nullptr, nullptr, s);
+    return fused_finalize(im, slabs, grid / 2, lpart, grid, d, fo, inv_count, grads, losses, s);
 }
 
 }  // namespace ppo2hip

@@ -82,7 +82,6 @@ struct Fused16Args {
     float cliprange, ent_coef, vf_coef, inv_count;
     float *slabs;            // [2 trunks][nwg_per_trunk][SLAB]
     double *loss_partial;    // [gridDim.x][kLossStride]
-    unsigned *ticket;        // cleared here for the finalize launch that follows
 };
 
 // The rollout arrays are read through buffer descriptors: 32-bit byte offsets (one register per
@@ -116,7 +115,6 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    if (blockIdx.x == 0 && tid == 0) *g.ticket = 0u;
     const bool is_value = (blockIdx.x & 1) != 0;
     const int nwg_trunk = gridDim.x >> 1;
     const int wg_in_trunk = blockIdx.x >> 1;
@@ -680,13 +678,13 @@ int mlp_fused16_grid() { return 256; }   // one 512-thread workgroup per CU (LDS
 
 size_t mlp_fused16_workspace_bytes() {
     return align_up((size_t)mlp_fused16_grid() * f16::SLAB * sizeof(float), 256) +
-           align_up((size_t)mlp_fused16_grid() * f16::kLossStride * sizeof(double), 256) + kTicketBytes;
+           align_up((size_t)mlp_fused16_grid() * f16::kLossStride * sizeof(double), 256);
 }
 
 int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params,
                      const FusedOffsets &fo, const ppo2hip_rollout &ro, const int32_t *idx, int64_t B,
                      const double *stats, float cliprange, double inv_count, float *grads, float *losses, void *ws,
-                     size_t ws_bytes, const AdamFuse *adam, hipStream_t s) {
+                     size_t ws_bytes, hipStream_t s) {
     using namespace f16;
     if (ws_bytes < mlp_fused16_workspace_bytes()) {
         set_error("mlp_fused16_grad: workspace too small");
@@ -695,7 +693,6 @@ int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, 
     const int grid = mlp_fused16_grid();
     float *slabs = (float *)ws;
     double *lpart = (double *)((char *)ws + align_up((size_t)grid * SLAB * sizeof(float), 256));
-    unsigned *ticket = (unsigned *)((char *)lpart + align_up((size_t)grid * kLossStride * sizeof(double), 256));
     Fused16Args g;
     g.obs = (const float *)ro.obs; g.actions = ro.actions; g.returns = ro.returns; g.values = ro.values;
     g.neglogpacs = ro.neglogpacs; g.advs = ro.advs; g.adv_f64 = ro.adv_f64; g.T = ro.T; g.E = ro.E; g.n = ro.n;
@@ -704,7 +701,7 @@ int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, 
     g.logstd_off = fo.logstd; g.D = d.ob_dim; g.A = d.ac_dim; g.R = d.nvalue; g.dist = d.dist;
     g.upstream = lc.upstream; g.cliprange = cliprange; g.ent_coef = lc.ent_coef;
     g.vf_coef = lc.upstream ? lc.vf_coef : 1.0f; g.inv_count = (float)inv_count;
-    g.slabs = slabs; g.loss_partial = lpart; g.ticket = ticket;
+    g.slabs = slabs; g.loss_partial = lpart;
     if (d.ob_dim <= 7) hipLaunchKernelGGL((mlp_fused16_kernel<2, false>), dim3(grid), dim3(kThreads), 0, s, g);
     else if (d.ob_dim <= 15) hipLaunchKernelGGL((mlp_fused16_kernel<4, false>), dim3(grid), dim3(kThreads), 0, s, g);
     else if (d.ob_dim <= 19) hipLaunchKernelGGL((mlp_fused16_kernel<5, true>), dim3(grid), dim3(kThreads), 0, s, g);
@@ -713,7 +710,7 @@ int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, 
     if (rc) return rc;
     FusedImage im;
     im.slab_elems = SLAB; im.s_w1 = S_W1; im.s_w2 = S_W2; im.s_wh = S_WH; im.s_bh = S_BH; im.head_cols = 16; im.s_logstd = S_BH + 8;
-    return fused_finalize(im, slabs, grid / 2, lpart, grid, d, fo, inv_count, grads, losses, adam, ticket, s);
+    return fused_finalize(im, slabs, grid / 2, lpart, grid, d, fo, inv_count, grads, losses, s);
 }
 
 }  // namespace ppo2hip

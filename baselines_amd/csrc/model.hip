@@ -203,13 +203,9 @@ static int mlp_path_choice(const ppo2hip_policy_desc &d, const ppo2hip_rollout &
     return f16 ? 16 : (f32 ? 32 : 0);
 }
 
-// adam != null: the caller wants the optimiser applied right after the gradient; *adam_done tells
-// whether this route did it inside its own launches (else the caller runs the Adam kernel).
 static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const Layout &L, const float *p,
                     const ppo2hip_rollout &ro, const int32_t *idx, int64_t B, const double *stats, float cliprange,
-                    double inv_count, float *grads, float *losses, void *ws, size_t ws_bytes, hipStream_t s,
-                    const AdamFuse *adam = nullptr, bool *adam_done = nullptr) {
-    if (adam_done) *adam_done = false;
+                    double inv_count, float *grads, float *losses, void *ws, size_t ws_bytes, hipStream_t s) {
     Carver c(ws, ws_bytes);
     MlpBuf w;
     carve_mlp(d, B, c, w, true);
@@ -223,12 +219,9 @@ static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
     if (path) {
         FusedOffsets fo{L.off("pi_fc1/w"), L.off("pi_fc2/w"), L.off("pi/w"), L.off("vf_fc1/w"), L.off("vf_fc2/w"),
                         L.off("vf/w"), gauss ? L.off("logstd") : 0};
-        if (path == 16) {
-            const bool fuse = adam && adam->P <= kAdamFuseMax;
-            if (adam_done) *adam_done = fuse;
+        if (path == 16)
             return mlp_fused16_grad(d, lc, p, fo, ro, idx, B, stats, cliprange, inv_count, grads, losses, w.fused,
-                                    w.fused_bytes, fuse ? adam : nullptr, s);
-        }
+                                    w.fused_bytes, s);
         return mlp_fused_grad(d, lc, p, fo, ro, idx, B, stats, cliprange, inv_count, grads, losses, w.fused,
                               w.fused_bytes, s);
     }
@@ -684,38 +677,14 @@ extern "C" int ppo2hip_ppo_epoch(const ppo2hip_policy_desc *desc, const ppo2hip_
     const int64_t nmb = N / nbatch_train;
     const int64_t P = ppo2hip_param_count(desc);
     if (P < 0) return PPO2HIP_EINVAL;
-    PPO2HIP_REQUIRE(loss && params && rollout && grads && workspace, "ppo_epoch: null pointer");
-    Layout L;
-    int rc = build_layout(*desc, L);
-    if (rc) return rc;
     for (int64_t j = 0; j < nmb; j++) {
-        const int64_t t = t_first + j;
-        bool adam_done = false;
-        if (desc->kind == PPO2HIP_POLICY_MLP) {
-            // routes that end in a reduction launch of their own let its last block apply the optimiser
-            PPO2HIP_REQUIRE(rollout->obs && rollout->actions && rollout->returns && rollout->values &&
-                            rollout->neglogpacs && rollout->advs && rollout->n > 0 &&
-                            (rollout->T == 0 || rollout->n == (int64_t)rollout->T * rollout->E),
-                            "ppo_epoch: bad rollout");
-            AdamFuse af;
-            af.theta = params; af.m = adam_m; af.v = adam_v; af.P = P;
-            af.a = (float)(lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t)));
-            af.beta1 = (float)beta1; af.beta2 = (float)beta2; af.eps = (float)epsilon; af.max_norm = (float)max_grad_norm;
-            af.header = (float *)adam_scratch;
-            rc = mlp_grad(*desc, *loss, L, params, *rollout, idx + j * nbatch_train, nbatch_train,
-                          stats ? stats + 3 * j : nullptr, cliprange, 1.0 / (double)nbatch_train, grads, losses + 8 * j,
-                          workspace, workspace_bytes, (hipStream_t)stream, &af, &adam_done);
-        } else {
-            rc = ppo2hip_ppo_grad(desc, loss, params, rollout, idx + j * nbatch_train, nbatch_train, nullptr, 0,
+        int rc = ppo2hip_ppo_grad(desc, loss, params, rollout, idx + j * nbatch_train, nbatch_train, nullptr, 0,
                                   stats ? stats + 3 * j : nullptr, cliprange, 1.0 / (double)nbatch_train, grads,
                                   losses + 8 * j, workspace, workspace_bytes, stream);
-        }
         if (rc) return rc;
-        if (!adam_done) {
-            rc = ppo2hip_adam_step(params, grads, adam_m, adam_v, P, lr, t, beta1, beta2, epsilon, 1.0, max_grad_norm,
-                                   adam_scratch, stream);
-            if (rc) return rc;
-        }
+        rc = ppo2hip_adam_step(params, grads, adam_m, adam_v, P, lr, t_first + j, beta1, beta2, epsilon, 1.0,
+                               max_grad_norm, adam_scratch, stream);
+        if (rc) return rc;
     }
     return PPO2HIP_OK;
 }

@@ -219,6 +219,11 @@ class Model(object):
         T, E = ro.T, ro.E
         N = T * E
         main = torch.cuda.current_stream()
+        # Keep at most two updates queued: a host that runs further ahead fills the launch queue, and the
+        # launch that then blocks holds the host until the queue has drained, after which the GPU starves.
+        inflight = self.__dict__.setdefault("_updates_inflight", [])
+        if len(inflight) >= 2:
+            inflight.pop(0).synchronize()
         rref = hip.RolloutRef(spec, ro.obs, ro.actions, ro.returns, ro.values, ro.neglogpacs, ro.advs, T, E,
                               ro.dones if spec.recurrent else None, ro.states)
         comm = self.comm if (self.comm is not None and self.comm.size > 1) else None
@@ -309,7 +314,11 @@ class Model(object):
         if comm is not None:
             comm.allreduce_sum_(out)
             out = out / comm.size
-        return out.float()
+        out = out.float()
+        queued = torch.cuda.Event()
+        queued.record(main)
+        inflight.append(queued)
+        return out
 
     def _train_on_rollout_global(self, lr, cliprange, ro, rref, noptepochs, nbatch_train):
         """Data-parallel update that reproduces the single-process one: every rank draws the

@@ -76,8 +76,8 @@ def test_update_epochs_match_oracle_and_index_stream(mods):
 
 
 def test_epoch_call_equals_per_minibatch_calls(mods):
-    """The one-call epoch loop (optimiser applied by the gradient's own reduction launch) and the
-    separate gradient + Adam calls per minibatch land on the same parameters, Adam moments and
+    """The one-call epoch loop and the separate gradient + Adam calls per minibatch (the path the
+    data-parallel mode and the timing instrumentation take) land on the same parameters, Adam moments and
     loss rows; so does a second update that continues from the first (step counter, run-ahead
     index job)."""
     sp, pol, cf = mods["spaces"], mods["policies"], mods["cf"]
