@@ -33,20 +33,23 @@ __global__ void gae_kernel(const float *__restrict__ rewards, const float *__res
     double nnt = 1.0 - (double)(last_dones[env] != 0);
     double last = 0.0;
 
-    int t = T - 1;
-    // main loop: UNROLL independent loads in flight per lane, the carry chain is arithmetic only
-    for (; t - (UNROLL - 1) >= 0; t -= UNROLL) {
+    // UNROLL steps per batch: their loads are independent and in flight together (one memory round
+    // trip per batch), the carry chain is arithmetic only.  The last batch is padded with clamped,
+    // unused loads instead of falling back to one round trip per step.
+    for (int t = T - 1; t >= 0; t -= UNROLL) {
         float rw[UNROLL], vl[UNROLL];
         uint8_t dn[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            const int64_t off = (int64_t)(t - u) * C + c;
+            const int tt = t - u >= 0 ? t - u : 0;
+            const int64_t off = (int64_t)tt * C + c;
             rw[u] = rewards[off];
             vl[u] = values[off];
-            dn[u] = dones[(int64_t)(t - u) * E + env];
+            dn[u] = dones[(int64_t)tt * E + env];
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
+            if (t - u < 0) break;
             const int64_t off = (int64_t)(t - u) * C + c;
             const double v = (double)vl[u];
             double delta = __dadd_rn((double)rw[u], __dmul_rn(__dmul_rn(gamma, nextvalue), nnt));
@@ -61,20 +64,128 @@ __global__ void gae_kernel(const float *__restrict__ rewards, const float *__res
             nnt = 1.0 - (double)(dn[u] != 0);   // dones[t] masks the step from t-1 to t
         }
     }
-    for (; t >= 0; t--) {
-        const int64_t off = (int64_t)t * C + c;
-        const float vf = values[off];
-        const double v = (double)vf;
-        double delta = __dadd_rn((double)rewards[off], __dmul_rn(__dmul_rn(gamma, nextvalue), nnt));
-        delta = __dsub_rn(delta, v);
-        last = __dadd_rn(delta, __dmul_rn(__dmul_rn(gl, nnt), last));
-        const float a = (float)last;
-        const float ret = __fadd_rn(a, vf);
-        advs[off] = a;
-        returns[off] = ret;
-        if (advs_ori) advs_ori[off] = __fsub_rn(ret, vf);
-        nextvalue = v;
-        nnt = 1.0 - (double)(dones[(int64_t)t * E + env] != 0);
+}
+
+// Same scan for rollouts with few columns (E * R of a few thousand), where one lane per column is bound
+// by the latency of its own loads and by the length of the per-step instruction sequence.  A 256-thread
+// block takes 16 columns and walks the rollout in 64-step chunks:
+//   all threads  : chunk loads (the next chunk's are in flight while this one is processed), then for
+//                  every element delta_t = (r_t + (gamma V_{t+1}) nt_{t+1}) - V_t and decay_t = (gamma lam) nt_{t+1}
+//                  — neither depends on the carry;
+//   16 lanes     : the carry chain alone, A_t = delta_t + decay_t A_{t+1}: one multiply and one add per step;
+//   all threads  : Ret = A + V, Ret - V, and the stores.
+// Every value goes through the operations of the step-by-step loop in the same order, so the bits are the same.
+constexpr int kGaeCols = 16, kGaeChunk = 64, kGaeThreads = 256;
+
+__global__ __launch_bounds__(kGaeThreads) void gae_tiled_kernel(
+    const float *__restrict__ rewards, const float *__restrict__ values, const uint8_t *__restrict__ dones,
+    const float *__restrict__ last_values, const uint8_t *__restrict__ last_dones, GammaVec gv, double lam, int T,
+    int E, int R, float *__restrict__ advs, float *__restrict__ returns, float *__restrict__ advs_ori) {
+    constexpr int N = kGaeChunk * kGaeCols, PER = N / kGaeThreads;
+    static_assert(PER == 4, "four elements per thread and chunk");
+    __shared__ double s_delta[N], s_decay[N];
+    __shared__ float s_vl[N + kGaeCols];               // s_vl / s_nn row 0 = carry-in (V and nonterminal of the step after
+    __shared__ double s_nn[N + kGaeCols];              // the chunk's first), rows 1.. = the chunk
+    const int64_t C = (int64_t)E * R;
+    const int64_t c0 = (int64_t)blockIdx.x * kGaeCols;
+    const int tid = threadIdx.x;
+    const int nchunks = (T + kGaeChunk - 1) / kGaeChunk;
+
+    // chunk k covers steps t0, t0 - 1, ... with t0 = T - 1 - k * chunk.  Two register sets: the loads of chunk
+    // k + 2 are issued while chunk k is processed, so they have a whole chunk's time to arrive.
+    auto fetch = [&](int k, float (&rw)[PER], float (&vl)[PER], uint8_t (&dn)[PER]) {
+        const int t0 = T - 1 - k * kGaeChunk;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int e = tid + i * kGaeThreads, tt = e / kGaeCols, j = e % kGaeCols;
+            const int t = t0 - tt >= 0 ? t0 - tt : 0;
+            const int64_t c = c0 + j < C ? c0 + j : C - 1;
+            rw[i] = rewards[(int64_t)t * C + c];
+            vl[i] = values[(int64_t)t * C + c];
+            dn[i] = dones[(int64_t)t * E + c / R];
+        }
+    };
+
+    // per-column constants of the elements this thread handles (column j = tid % 16 for all of them)
+    const int jcol = tid % kGaeCols;
+    const int64_t ccol = c0 + jcol < C ? c0 + jcol : C - 1;
+    const double gamma = gv.g[(int)(ccol % R)];
+    const double gl = __dmul_rn(gamma, lam);
+    double last = 0.0;                         // carry of column tid (scanner lanes)
+    const bool scanner = tid < kGaeCols && c0 + tid < C;
+    if (tid < kGaeCols) {
+        s_vl[tid] = last_values[ccol];
+        s_nn[tid] = 1.0 - (double)(last_dones[ccol / R] != 0);
+    }
+    auto chunk = [&](int k, float (&rw)[PER], float (&vl)[PER], uint8_t (&dn)[PER]) {
+        const int t0 = T - 1 - k * kGaeChunk;
+        const int steps = t0 + 1 < kGaeChunk ? t0 + 1 : kGaeChunk;
+        // raw values and nonterminal factors of the chunk, one row below their step (row 0 is the carry-in)
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int e = tid + i * kGaeThreads;
+            s_vl[kGaeCols + e] = vl[i];
+            s_nn[kGaeCols + e] = 1.0 - (double)(dn[i] != 0);      // dones[t] masks the step from t-1 to t
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int e = tid + i * kGaeThreads;
+            const double nv = (double)s_vl[e], nt = s_nn[e];      // the step after this one: one row up
+            s_delta[e] = __dsub_rn(__dadd_rn((double)rw[i], __dmul_rn(__dmul_rn(gamma, nv), nt)), (double)vl[i]);
+            s_decay[e] = __dmul_rn(gl, nt);
+        }
+        const float vkeep[PER] = {vl[0], vl[1], vl[2], vl[3]};
+        if (k + 2 < nchunks) fetch(k + 2, rw, vl, dn);            // this set is free again: its raw values are in LDS / vkeep
+        __syncthreads();
+        if (scanner) {
+            // the scanning lanes do nothing but the chain: the carry, still in double, goes back into the
+            // delta slot; rounding to float32 and the rest happen in the parallel phase below
+            constexpr int U = 8;
+            int tb = 0;
+            for (; tb + U <= steps; tb += U) {
+                double d[U], q[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    d[u] = s_delta[(tb + u) * kGaeCols + tid];
+                    q[u] = s_decay[(tb + u) * kGaeCols + tid];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    last = __dadd_rn(d[u], __dmul_rn(q[u], last));
+                    s_delta[(tb + u) * kGaeCols + tid] = last;
+                }
+            }
+            for (; tb < steps; tb++) {
+                last = __dadd_rn(s_delta[tb * kGaeCols + tid], __dmul_rn(s_decay[tb * kGaeCols + tid], last));
+                s_delta[tb * kGaeCols + tid] = last;
+            }
+        }
+        if (tid < kGaeCols) {       // carry-in of the next chunk = this chunk's last step
+            s_vl[tid] = s_vl[kGaeCols + (steps - 1) * kGaeCols + tid];
+            s_nn[tid] = s_nn[kGaeCols + (steps - 1) * kGaeCols + tid];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int e = tid + i * kGaeThreads, tt = e / kGaeCols, j = e % kGaeCols;
+            if (t0 - tt >= 0 && c0 + j < C) {
+                const int64_t off = (int64_t)(t0 - tt) * C + c0 + j;
+                const float a = (float)s_delta[e];
+                const float ret = __fadd_rn(a, vkeep[i]);
+                advs[off] = a;
+                returns[off] = ret;
+                if (advs_ori) advs_ori[off] = __fsub_rn(ret, vkeep[i]);
+            }
+        }
+    };
+    float rwA[PER], vlA[PER], rwB[PER], vlB[PER];
+    uint8_t dnA[PER], dnB[PER];
+    fetch(0, rwA, vlA, dnA);
+    if (nchunks > 1) fetch(1, rwB, vlB, dnB);
+    for (int k = 0; k < nchunks; k += 2) {
+        chunk(k, rwA, vlA, dnA);
+        if (k + 1 < nchunks) chunk(k + 1, rwB, vlB, dnB);
     }
 }
 
@@ -162,8 +273,14 @@ extern "C" int ppo2hip_gae_f32(const float *rewards, const float *values, const 
     const int64_t C = (int64_t)E * R;
     const int block = C <= 65536 ? 64 : 256;   // few columns: spread them over more CUs
     const int64_t grid = ceil_div(C, block);
-    hipLaunchKernelGGL(gae_kernel<8>, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, rewards,
-                       values, dones, last_values, last_dones, gv, lam, T, E, R, advs, returns, advs_ori);
+    // one lane per column fills the chip from about 64 K columns on; below that, blocks that stream chunks
+    // through LDS keep far more loads in flight per column
+    if (C < 65536 && T >= 32)
+        hipLaunchKernelGGL(gae_tiled_kernel, dim3((unsigned)ceil_div(C, kGaeCols)), dim3(kGaeThreads), 0, (hipStream_t)stream,
+                           rewards, values, dones, last_values, last_dones, gv, lam, T, E, R, advs, returns, advs_ori);
+    else
+        hipLaunchKernelGGL(gae_kernel<8>, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, rewards,
+                           values, dones, last_values, last_dones, gv, lam, T, E, R, advs, returns, advs_ori);
     return check_launch("gae_kernel");
 }
 

@@ -49,7 +49,8 @@ def test_gae_golden_bit_exact(hip, golden, name):
     np.testing.assert_array_equal(ori.cpu().numpy(), o_rets - g("values"))
 
 
-@pytest.mark.parametrize("T,E,R", [(1, 1, 1), (7, 3, 1), (256, 300, 1), (37, 129, 5), (128, 1024, 1), (9, 70, 8)])
+@pytest.mark.parametrize("T,E,R", [(1, 1, 1), (7, 3, 1), (256, 300, 1), (37, 129, 5), (128, 1024, 1), (9, 70, 8),
+                                   (130, 45, 3), (64, 16, 1), (65, 17, 2), (40, 70000, 1), (33, 9000, 8)])
 def test_gae_random_bit_exact(hip, T, E, R):
     rng = np.random.RandomState(T + E + R)
     rewards = rng.randn(T, E, R).astype(np.float32)
