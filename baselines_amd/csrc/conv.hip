@@ -14,66 +14,117 @@ struct ConvGeom {
     int IH, IW, Cin, KH, KW, S, OH, OW, Cout;
 };
 
+// pixel (b, oh, ow) of output row m, and the input offset of its patch's first element
+struct PatchRow {
+    int b, oh, ow;
+    int64_t base;
+};
+__device__ inline PatchRow patch_row(const ConvGeom &g, int64_t m) {
+    const int ohw = g.OH * g.OW;
+    PatchRow p;
+    p.b = (int)(m / ohw);
+    const int r = (int)(m - (int64_t)p.b * ohw);
+    p.oh = r / g.OW;
+    p.ow = r - p.oh * g.OW;
+    p.base = (((int64_t)p.b * g.IH + p.oh * g.S) * g.IW + p.ow * g.S) * g.Cin;
+    return p;
+}
+// offset of tap k = (kh, kw, ci) inside a patch
+__device__ inline int tap_offset(const ConvGeom &g, int64_t k) {
+    const int kc = g.KW * g.Cin;
+    const int kh = (int)k / kc;
+    return kh * g.IW * g.Cin + ((int)k - kh * kc);
+}
+
 template <bool U8>
 struct Im2col {   // A(m, k)
     static constexpr bool kInnerFast = true;
+    typedef int64_t Row;
+    typedef int Col;
     const void *x;
     ConvGeom g;
-    __device__ float operator()(int64_t m, int64_t k) const {
-        const int ohw = g.OH * g.OW;
-        const int64_t b = m / ohw;
-        const int r = (int)(m - b * ohw);
-        const int oh = r / g.OW, ow = r - oh * g.OW;
-        const int kc = g.KW * g.Cin;
-        const int kh = (int)k / kc;
-        const int r2 = (int)k - kh * kc;
-        const int kw = r2 / g.Cin, ci = r2 - kw * g.Cin;
-        const int64_t off = ((b * g.IH + oh * g.S + kh) * g.IW + ow * g.S + kw) * g.Cin + ci;
-        if (U8) return (float)((const uint8_t *)x)[off] / 255.0f;
-        return ((const float *)x)[off];
+    __device__ Row row(int64_t m) const { return patch_row(g, m).base; }
+    __device__ Col col(int64_t k) const { return tap_offset(g, k); }
+    __device__ float at(const Row &r, const Col &c) const {
+        if (U8) return (float)((const uint8_t *)x)[r + c] / 255.0f;
+        return ((const float *)x)[r + c];
     }
 };
 
 template <bool U8>
 struct Im2colT {   // A(i = k, kk = m), row `ones_row` = 1
     static constexpr bool kInnerFast = false;
+    typedef int Row;          // tap offset, or -1 for the row of ones
+    typedef PatchRow Col;
     Im2col<U8> c;
     int64_t ones_row;
-    __device__ float operator()(int64_t i, int64_t m) const { return i == ones_row ? 1.f : c(m, i); }
+    __device__ Row row(int64_t i) const { return i == ones_row ? -1 : tap_offset(c.g, i); }
+    __device__ Col col(int64_t m) const { return patch_row(c.g, m); }
+    __device__ void advance_col(Col &p, int d) const {      // d output pixels further on
+        const ConvGeom &g = c.g;
+        p.ow += d;
+        while (p.ow >= g.OW) { p.ow -= g.OW; p.oh++; }
+        while (p.oh >= g.OH) { p.oh -= g.OH; p.b++; }
+        p.base = (((int64_t)p.b * g.IH + p.oh * g.S) * g.IW + p.ow * g.S) * g.Cin;
+    }
+    __device__ float at(const Row &r, const Col &p) const { return r < 0 ? 1.f : c.at(p.base, r); }
 };
+
+struct PixelRow {   // pixel (ih, iw) of image b in the dgrad row space; bbase = offset of dY[b, 0, 0, 0]
+    int64_t bbase;
+    int ih, iw;
+};
+struct TapCol {
+    int kh, kw, co;
+};
+__device__ inline TapCol tap_col(int KW, int Cout, int64_t k) {
+    const int kc = KW * Cout;
+    TapCol t;
+    t.kh = (int)k / kc;
+    const int r2 = (int)k - t.kh * kc;
+    t.kw = r2 / Cout;
+    t.co = r2 - t.kw * Cout;
+    return t;
+}
 
 struct DgradCol {   // A(m = (b,ih,iw), k = (kh,kw,co)) = dY[b, (ih-kh)/s, (iw-kw)/s, co] or 0
     static constexpr bool kInnerFast = true;
+    typedef PixelRow Row;
+    typedef TapCol Col;
     const float *dy;
     ConvGeom g;
-    __device__ float operator()(int64_t m, int64_t k) const {
+    __device__ Row row(int64_t m) const {
         const int ihw = g.IH * g.IW;
-        const int64_t b = m / ihw;
-        const int r = (int)(m - b * ihw);
-        const int ih = r / g.IW, iw = r - ih * g.IW;
-        const int kc = g.KW * g.Cout;
-        const int kh = (int)k / kc;
-        const int r2 = (int)k - kh * kc;
-        const int kw = r2 / g.Cout, co = r2 - kw * g.Cout;
-        const int th = ih - kh, tw = iw - kw;
+        const int b = (int)(m / ihw);
+        const int r = (int)(m - (int64_t)b * ihw);
+        Row p;
+        p.ih = r / g.IW;
+        p.iw = r - p.ih * g.IW;
+        p.bbase = (int64_t)b * g.OH * g.OW * g.Cout;
+        return p;
+    }
+    __device__ Col col(int64_t k) const { return tap_col(g.KW, g.Cout, k); }
+    __device__ float at(const Row &p, const Col &t) const {
+        const int th = p.ih - t.kh, tw = p.iw - t.kw;
         if (th < 0 || tw < 0) return 0.f;
         const int oh = th / g.S, ow = tw / g.S;
         if (oh * g.S != th || ow * g.S != tw || oh >= g.OH || ow >= g.OW) return 0.f;
-        return dy[((b * g.OH + oh) * g.OW + ow) * g.Cout + co];
+        return dy[p.bbase + (int64_t)(oh * g.OW + ow) * g.Cout + t.co];
     }
 };
 
 struct DgradW {   // B(k = (kh,kw,co), n = ci) = W[kh, kw, ci, co]
     static constexpr bool kInnerFast = false;
+    typedef int Row;
+    typedef int Col;
     const float *w;
     ConvGeom g;
-    __device__ float operator()(int64_t k, int64_t n) const {
-        const int kc = g.KW * g.Cout;
-        const int kh = (int)k / kc;
-        const int r2 = (int)k - kh * kc;
-        const int kw = r2 / g.Cout, co = r2 - kw * g.Cout;
-        return w[((int64_t)(kh * g.KW + kw) * g.Cin + n) * g.Cout + co];
+    __device__ Row row(int64_t k) const {
+        const TapCol t = tap_col(g.KW, g.Cout, k);
+        return (t.kh * g.KW + t.kw) * g.Cin * g.Cout + t.co;
     }
+    __device__ Col col(int64_t n) const { return (int)n * g.Cout; }
+    __device__ float at(const Row &r, const Col &c) const { return w[r + c]; }
 };
 
 static ConvGeom geom(const ConvShape &c) {
@@ -104,11 +155,86 @@ int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape 
     *nslabs = n;
     RowMajor Bm{dY, c.Cout};
     EpiSlab ep{slabs, c.Cout, (int64_t)(K + 1) * c.Cout};
-    if (x_u8) return launch_gemm(Im2colT<true>{Im2col<true>{X, geom(c)}, K}, Bm, ep, K + 1, c.Cout, M, n, s, "conv_wgrad");
-    return launch_gemm(Im2colT<false>{Im2col<false>{X, geom(c)}, K}, Bm, ep, K + 1, c.Cout, M, n, s, "conv_wgrad");
+    const bool sep = wgrad_bias_separately(K);         // ones-row only where it does not cost an extra row tile
+    const int64_t ones = sep ? -1 : K, rows = sep ? K : K + 1;
+    int rc;
+    if (x_u8) rc = launch_gemm(Im2colT<true>{Im2col<true>{X, geom(c)}, ones}, Bm, ep, rows, c.Cout, M, n, s, "conv_wgrad");
+    else rc = launch_gemm(Im2colT<false>{Im2col<false>{X, geom(c)}, ones}, Bm, ep, rows, c.Cout, M, n, s, "conv_wgrad");
+    if (rc || !sep) return rc;
+    return slab_bias_rows(dY, c.Cout, M, K, c.Cout, slabs, n, s);
 }
 
+// Strided convolutions: an input pixel (ih, iw) only meets the taps with kh = ih, kw = iw (mod S), so the input
+// gradient splits into S x S products, one per parity class of (ih, iw), each over (KH/S)(KW/S) Cout terms
+// instead of KH KW Cout of which all but 1/S^2 are zero.
+struct DgradColP {   // A(m' = (b, ih', iw'), k' = (kh', kw', co)),  ih = S ih' + ph, kh = ph + S kh'  =>  oh = ih' - kh'
+    static constexpr bool kInnerFast = true;
+    typedef PixelRow Row;     // (ih', iw')
+    typedef TapCol Col;       // (kh', kw', co)
+    const float *dy;
+    ConvGeom g;
+    int ph, pw, IHp, IWp, KWp;
+    __device__ Row row(int64_t m) const {
+        const int ihw = IHp * IWp;
+        const int b = (int)(m / ihw);
+        const int r = (int)(m - (int64_t)b * ihw);
+        Row p;
+        p.ih = r / IWp;
+        p.iw = r - p.ih * IWp;
+        p.bbase = (int64_t)b * g.OH * g.OW * g.Cout;
+        return p;
+    }
+    __device__ Col col(int64_t k) const { return tap_col(KWp, g.Cout, k); }
+    __device__ float at(const Row &p, const Col &t) const {
+        const int oh = p.ih - t.kh, ow = p.iw - t.kw;
+        if (oh < 0 || ow < 0 || oh >= g.OH || ow >= g.OW) return 0.f;
+        return dy[p.bbase + (int64_t)(oh * g.OW + ow) * g.Cout + t.co];
+    }
+};
+struct DgradWP {   // B(k' = (kh', kw', co), n = ci) = W[ph + S kh', pw + S kw', ci, co]
+    static constexpr bool kInnerFast = false;
+    typedef int Row;
+    typedef int Col;
+    const float *w;
+    ConvGeom g;
+    int ph, pw, KWp;
+    __device__ Row row(int64_t k) const {
+        const TapCol t = tap_col(KWp, g.Cout, k);
+        return ((ph + g.S * t.kh) * g.KW + pw + g.S * t.kw) * g.Cin * g.Cout + t.co;
+    }
+    __device__ Col col(int64_t n) const { return (int)n * g.Cout; }
+    __device__ float at(const Row &r, const Col &c) const { return w[r + c]; }
+};
+struct EpiActGradP {   // row m' of a parity class -> pixel (b, S ih' + ph, S iw' + pw) of dX, times relu'(X)
+    float *dX;
+    const float *Xact;
+    ConvGeom g;
+    int ph, pw, IHp, IWp;
+    __device__ void operator()(int64_t m, int64_t n, float v, int) const {
+        const int ihw = IHp * IWp;
+        const int64_t b = m / ihw;
+        const int r = (int)(m - b * ihw);
+        const int ihp = r / IWp, iwp = r - ihp * IWp;
+        const int64_t off = ((b * g.IH + g.S * ihp + ph) * g.IW + g.S * iwp + pw) * g.Cin + n;
+        dX[off] = Xact[off] > 0.f ? v : 0.f;
+    }
+};
+
 int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, const ConvShape &c, hipStream_t s) {
+    if (c.stride > 1 && c.KH % c.stride == 0 && c.KW % c.stride == 0) {
+        const int S = c.stride, KHp = c.KH / S, KWp = c.KW / S;
+        for (int ph = 0; ph < S; ph++)
+            for (int pw = 0; pw < S; pw++) {
+                const int IHp = (c.IH - ph + S - 1) / S, IWp = (c.IW - pw + S - 1) / S;
+                if (IHp <= 0 || IWp <= 0) continue;
+                const int64_t M = (int64_t)c.B * IHp * IWp;
+                const int K = KHp * KWp * c.Cout;
+                int rc = launch_gemm(DgradColP{dY, geom(c), ph, pw, IHp, IWp, KWp}, DgradWP{W, geom(c), ph, pw, KWp},
+                                     EpiActGradP{dX, Xact, geom(c), ph, pw, IHp, IWp}, M, c.Cin, K, 1, s, "conv_dgrad");
+                if (rc) return rc;
+            }
+        return 0;
+    }
     const int64_t M = (int64_t)c.B * c.IH * c.IW;
     const int K = c.KH * c.KW * c.Cout;
     EpiActGrad ep{dX, c.Cin, Xact, c.Cin, ACT_RELU, 0};

@@ -23,6 +23,8 @@ int fc_dgrad(const float *dY, int lddy, const float *W, int Kin, int N, const fl
     return launch_gemm(A, B, ep, M, Kin, N, 1, s, "fc_dgrad");
 }
 
+bool wgrad_bias_separately(int Kin);
+
 static int pick_slabs(int64_t S, int64_t tiles) {
     // enough workgroups to fill 256 CUs a few times over, at least 256 sample rows per slab
     int64_t want = ceil_div(1024, tiles > 0 ? tiles : 1);
@@ -34,8 +36,48 @@ static int pick_slabs(int64_t S, int64_t tiles) {
 }
 
 int wgrad_max_slabs(int64_t S, int Kin, int N) {
-    const int64_t tiles = ceil_div(Kin + 1, (Kin + 1) <= 64 ? 64 : 128) * ceil_div(N, GEMM_BN);
+    const int rows = wgrad_bias_separately(Kin) ? Kin : Kin + 1;
+    const int64_t tiles = ceil_div(rows, (Kin + 1) <= 64 ? 64 : 128) * ceil_div(N, N <= 32 ? 32 : GEMM_BN);
     return pick_slabs(S, tiles);
+}
+
+// Column sums of dY over each slab's rows, written to row Kin of that slab: the bias gradient where the
+// ones-row would cost the product a whole extra row tile (Kin a multiple of the tile height).
+__global__ __launch_bounds__(256) void slab_colsum_kernel(const float *__restrict__ dY, int64_t lddy, int64_t S, int N,
+                                                          int64_t klen, float *__restrict__ slabs, int64_t zstride,
+                                                          int64_t row_off) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int64_t z = blockIdx.y;
+    const int64_t r0 = z * klen, r1 = r0 + klen < S ? r0 + klen : S;
+    float acc = 0.f;
+    if (n < N) {
+        constexpr int U = 8;
+        for (int64_t r = r0 + grp; r < r1; r += 4 * U) {
+            float x[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) x[u] = r + 4 * u < r1 ? dY[(r + 4 * u) * lddy + n] : 0.f;
+#pragma unroll
+            for (int u = 0; u < U; u++) acc += x[u];
+        }
+    }
+    part[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0 && n < N) slabs[z * zstride + row_off + n] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+bool wgrad_bias_separately(int Kin) {
+    const int tile = (Kin + 1) <= 64 ? 64 : 128;
+    return Kin % tile == 0;
+}
+
+int slab_bias_rows(const float *dY, int lddy, int64_t S, int Kin, int N, float *slabs, int nslabs, hipStream_t s) {
+    int64_t klen = ceil_div(S > 0 ? S : 1, nslabs);
+    klen = ceil_div(klen, GEMM_BK) * GEMM_BK;       // the slab boundaries launch_gemm uses
+    hipLaunchKernelGGL(slab_colsum_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)nslabs), dim3(256), 0, s, dY,
+                       (int64_t)lddy, S, N, klen, slabs, (int64_t)(Kin + 1) * N, (int64_t)Kin * N);
+    return check_launch("slab_colsum_kernel");
 }
 
 int fc_wgrad_slabs(const float *X, int ldx, const float *dY, int lddy, int64_t S, int Kin, int N,
@@ -43,9 +85,15 @@ int fc_wgrad_slabs(const float *X, int ldx, const float *dY, int lddy, int64_t S
     int n = wgrad_max_slabs(S, Kin, N);
     if (n > max_slabs) n = max_slabs;
     *nslabs = n;
-    TransposedOnes A{X, ldx, Kin};   // A(i = kin, k = sample) = X[sample][kin]; row Kin = 1
     RowMajor B{dY, lddy};
     EpiSlab ep{slabs, N, (int64_t)(Kin + 1) * N};
+    if (wgrad_bias_separately(Kin)) {
+        TransposedOnes A{X, ldx, -1};    // no ones-row: rows 0 .. Kin-1 only
+        int rc = launch_gemm(A, B, ep, Kin, N, S, n, s, "fc_wgrad");
+        if (rc) return rc;
+        return slab_bias_rows(dY, lddy, S, Kin, N, slabs, n, s);
+    }
+    TransposedOnes A{X, ldx, Kin};   // A(i = kin, k = sample) = X[sample][kin]; row Kin = 1
     return launch_gemm(A, B, ep, Kin + 1, N, S, n, s, "fc_wgrad");
 }
 

@@ -2,7 +2,8 @@
 // layers (plain / transposed operands), implicit-GEMM convolutions and weight-gradient
 // products (split over the sample axis into slabs) all share one LDS-tiled main loop.
 //
-// Tile: BM x 64 x 16, 256 threads = 4 wave64.  v_mfma_f32_32x32x2_f32 is an exact fp32
+// Tile: BM x BN x 16 (128 x 64, 64 x 64 or, for outputs of at most 32 columns, 128 x 32), 256 threads =
+// 4 wave64.  v_mfma_f32_32x32x2_f32 is an exact fp32
 // fma chain, so results are reproducible and within fp32 rounding of a float64 reference.
 //   operand lanes : A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
 //   result lanes  : C[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
@@ -16,26 +17,32 @@ namespace ppo2hip {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GEMM_BN = 64;
+constexpr int GEMM_BN = 64;        // widest tile
 constexpr int GEMM_BK = 16;
 constexpr int GEMM_THREADS = 256;
 
-// Loader concept:   float operator()(int64_t row, int64_t col) const  — A: (m, k), B: (k, n);
-//                   out-of-range coordinates are never requested.
-//                   static constexpr bool kInnerFast — true when the SECOND coordinate is the
-//                   contiguous one in memory (drives the thread->element mapping for coalescing).
+// Loader concept (A: coordinates (m, k), B: (k, n)); out-of-range coordinates are never requested:
+//     Row row(int64_t r) const;  Col col(int64_t c) const;      what the element address owes to each coordinate
+//     void advance_col(Col &, int d) const;  void advance_row(Row &, int d) const;   move a coordinate by d >= 0
+//     float at(const Row &, const Col &) const;
+//     static constexpr bool kInnerFast — true when the SECOND coordinate is the contiguous one in memory
+//                                        (drives the thread->element mapping for coalescing).
+//   A thread's elements share one coordinate and differ in the other, and only the k coordinate moves from
+//   slab to slab, so the index arithmetic of an implicit-GEMM loader (divisions that split a row number into
+//   image / pixel, a column into tap / channel) runs once per tile or once per slab instead of once per element.
 // Epilogue concept: void operator()(int64_t m, int64_t n, float acc, int z) const
 
-// WM = number of wave rows (4: BM = 128, each wave 32 x 64; 2: BM = 64, each wave 32 x 32)
-template <class AL, class BL, class EP, int WM>
+// WM = number of wave rows, NB = 32-column blocks per wave:
+//   <4, 2>: 128 x 64, each wave 32 x 64;  <2, 1>: 64 x 64, each wave 32 x 32;  <4, 1>: 128 x 32, each wave 32 x 32
+template <class AL, class BL, class EP, int WM, int NB>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, int64_t M, int N, int64_t K,
                                                             int64_t klen) {
     constexpr int BM = 32 * WM;
     constexpr int WN = 4 / WM;              // wave columns
-    constexpr int NB = GEMM_BN / 32 / WN;   // 32-col blocks per wave (2 or 1)
-    constexpr int LDA = BM + 1, LDB = GEMM_BN + 1;
+    constexpr int BN = 32 * WN * NB;
+    constexpr int LDA = BM + 1, LDB = BN + 1;
     constexpr int A_PER = BM * GEMM_BK / GEMM_THREADS;
-    constexpr int B_PER = GEMM_BN * GEMM_BK / GEMM_THREADS;
+    constexpr int B_PER = BN * GEMM_BK / GEMM_THREADS;
     __shared__ float As[GEMM_BK * LDA];
     __shared__ float Bs[GEMM_BK * LDB];
 
@@ -43,7 +50,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * GEMM_BN;
+    const int n0 = blockIdx.y * BN;
     const int z = blockIdx.z;
     const int64_t kbeg = (int64_t)z * klen;
     const int64_t kend = kbeg + klen < K ? kbeg + klen : K;
@@ -56,25 +63,76 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
 
     float areg[A_PER], breg[B_PER];
 
-    auto fetch = [&](int64_t k0) {
+    // thread -> element mapping (element e of the thread is tile entry lin = tid + e * 256)
+    //   A, kInnerFast : k = lin % 16 is the thread's own, rows differ with e          (row contexts: once)
+    //   A, otherwise  : m = lin % BM is the thread's own, k differs with e and slab    (col contexts: advanced)
+    //   B, kInnerFast : n = lin % BN is the thread's own, k differs with e and slab    (row contexts: advanced)
+    //   B, otherwise  : k = lin % 16 is the thread's own, n differs with e             (col contexts: once)
+    constexpr int A_KSTEP = GEMM_THREADS / BM;          // k distance between a thread's elements (A, m-fast mapping)
+    constexpr int B_KSTEP = GEMM_THREADS / BN;
+    typename AL::Row arow[AL::kInnerFast ? A_PER : 1];
+    typename AL::Col acol[AL::kInnerFast ? 1 : A_PER];
+    typename BL::Row brow[BL::kInnerFast ? B_PER : 1];
+    typename BL::Col bcol[BL::kInnerFast ? 1 : B_PER];
+    bool a_ok[AL::kInnerFast ? A_PER : 1], b_ok[BL::kInnerFast ? 1 : B_PER];
+    if constexpr (AL::kInnerFast) {
 #pragma unroll
         for (int e = 0; e < A_PER; e++) {
-            const int lin = tid + e * GEMM_THREADS;
-            int ml, kl;
-            if (AL::kInnerFast) { kl = lin % GEMM_BK; ml = lin / GEMM_BK; }
-            else { ml = lin % BM; kl = lin / BM; }
-            const int64_t m = m0 + ml, k = k0 + kl;
-            areg[e] = (m < M && k < kend) ? a(m, k) : 0.f;
+            const int64_t m = m0 + (tid + e * GEMM_THREADS) / GEMM_BK;
+            a_ok[e] = m < M;
+            arow[e] = a.row(a_ok[e] ? m : 0);
         }
+    } else {
+        const int64_t m = m0 + tid % BM;
+        a_ok[0] = m < M;
+        arow[0] = a.row(a_ok[0] ? m : 0);
+#pragma unroll
+        for (int e = 0; e < A_PER; e++) acol[e] = a.col(kbeg + tid / BM + e * A_KSTEP);
+    }
+    if constexpr (BL::kInnerFast) {
+        const int n = n0 + tid % BN;
+        b_ok[0] = n < N;
+        bcol[0] = b.col(b_ok[0] ? n : 0);
+#pragma unroll
+        for (int e = 0; e < B_PER; e++) brow[e] = b.row(kbeg + tid / BN + e * B_KSTEP);
+    } else {
 #pragma unroll
         for (int e = 0; e < B_PER; e++) {
-            const int lin = tid + e * GEMM_THREADS;
-            int kl, nl;
-            if (BL::kInnerFast) { nl = lin % GEMM_BN; kl = lin / GEMM_BN; }
-            else { kl = lin % GEMM_BK; nl = lin / GEMM_BK; }
-            const int64_t k = k0 + kl;
-            const int n = n0 + nl;
-            breg[e] = (k < kend && n < N) ? b(k, n) : 0.f;
+            const int n = n0 + (tid + e * GEMM_THREADS) / GEMM_BK;
+            b_ok[e] = n < N;
+            bcol[e] = b.col(b_ok[e] ? n : 0);
+        }
+    }
+
+    // loads slab [k0, k0 + 16); the advancing contexts stand at k0 on entry and at k0 + 16 on exit
+    auto fetch = [&](int64_t k0) {
+        if constexpr (AL::kInnerFast) {
+            const int64_t k = k0 + tid % GEMM_BK;
+            const bool kok = k < kend;
+            acol[0] = a.col(kok ? k : kbeg);
+#pragma unroll
+            for (int e = 0; e < A_PER; e++) areg[e] = (kok && a_ok[e]) ? a.at(arow[e], acol[0]) : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < A_PER; e++) {
+                const int64_t k = k0 + tid / BM + e * A_KSTEP;
+                areg[e] = (a_ok[0] && k < kend) ? a.at(arow[0], acol[e]) : 0.f;
+                a.advance_col(acol[e], GEMM_BK);
+            }
+        }
+        if constexpr (BL::kInnerFast) {
+#pragma unroll
+            for (int e = 0; e < B_PER; e++) {
+                const int64_t k = k0 + tid / BN + e * B_KSTEP;
+                breg[e] = (b_ok[0] && k < kend) ? b.at(brow[e], bcol[0]) : 0.f;
+                b.advance_row(brow[e], GEMM_BK);
+            }
+        } else {
+            const int64_t k = k0 + tid % GEMM_BK;
+            const bool kok = k < kend;
+            brow[0] = b.row(kok ? k : kbeg);
+#pragma unroll
+            for (int e = 0; e < B_PER; e++) breg[e] = (kok && b_ok[e]) ? b.at(brow[0], bcol[e]) : 0.f;
         }
     };
     auto stash = [&]() {
@@ -90,7 +148,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
         for (int e = 0; e < B_PER; e++) {
             const int lin = tid + e * GEMM_THREADS;
             int kl, nl;
-            if (BL::kInnerFast) { nl = lin % GEMM_BN; kl = lin / GEMM_BN; }
+            if (BL::kInnerFast) { nl = lin % BN; kl = lin / BN; }
             else { kl = lin % GEMM_BK; nl = lin / GEMM_BK; }
             Bs[kl * LDB + nl] = breg[e];
         }
@@ -133,39 +191,60 @@ inline int launch_gemm(const AL &a, const BL &b, const EP &ep, int64_t M, int N,
     int64_t klen = ceil_div(K > 0 ? K : 1, nsplit);
     klen = ceil_div(klen, GEMM_BK) * GEMM_BK;
     const bool small_m = M <= 64;
-    const int BM = small_m ? 64 : 128;
+    const bool narrow = !small_m && N <= 32;        // half of a 64-column tile would multiply zeros
+    const int BM = small_m ? 64 : 128, BN = narrow ? 32 : 64;
     const int64_t gx = ceil_div(M, BM);
     if (gx > 0x7fffffffll || nsplit > 65535) {
         set_error("%s: grid too large", what);
         return PPO2HIP_EINVAL;
     }
-    dim3 grid((unsigned)gx, (unsigned)ceil_div(N, GEMM_BN), (unsigned)nsplit);
+    dim3 grid((unsigned)gx, (unsigned)ceil_div(N, BN), (unsigned)nsplit);
     if (small_m)
-        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 2>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
+        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 2, 1>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
+    else if (narrow)
+        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 1>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
     else
-        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
+        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 2>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
     return check_launch(what);
 }
 
 // ---- loaders ---------------------------------------------------------------------------
 struct RowMajor {   // element (r, c) at p[r*ld + c]
     static constexpr bool kInnerFast = true;
+    typedef int64_t Row;
+    typedef int64_t Col;
     const float *p;
     int64_t ld;
-    __device__ float operator()(int64_t r, int64_t c) const { return p[r * ld + c]; }
+    __device__ Row row(int64_t r) const { return r * ld; }
+    __device__ Col col(int64_t c) const { return c; }
+    __device__ void advance_row(Row &r, int d) const { r += d * ld; }
+    __device__ void advance_col(Col &c, int d) const { c += d; }
+    __device__ float at(const Row &r, const Col &c) const { return p[r + c]; }
 };
 struct Transposed {  // element (r, c) at p[c*ld + r]
     static constexpr bool kInnerFast = false;
+    typedef int64_t Row;
+    typedef int64_t Col;
     const float *p;
     int64_t ld;
-    __device__ float operator()(int64_t r, int64_t c) const { return p[c * ld + r]; }
+    __device__ Row row(int64_t r) const { return r; }
+    __device__ Col col(int64_t c) const { return c * ld; }
+    __device__ void advance_row(Row &r, int d) const { r += d; }
+    __device__ void advance_col(Col &c, int d) const { c += d * ld; }
+    __device__ float at(const Row &r, const Col &c) const { return p[r + c]; }
 };
 struct TransposedOnes {  // as Transposed, plus a row `ones_row` of 1.0 (folds the bias gradient in)
     static constexpr bool kInnerFast = false;
+    typedef int64_t Row;     // -1 = the row of ones
+    typedef int64_t Col;
     const float *p;
     int64_t ld;
     int64_t ones_row;
-    __device__ float operator()(int64_t r, int64_t c) const { return r == ones_row ? 1.f : p[c * ld + r]; }
+    __device__ Row row(int64_t r) const { return r == ones_row ? -1 : r; }
+    __device__ Col col(int64_t c) const { return c * ld; }
+    __device__ void advance_row(Row &, int) const {}
+    __device__ void advance_col(Col &c, int d) const { c += d * ld; }
+    __device__ float at(const Row &r, const Col &c) const { return r < 0 ? 1.f : p[r + c]; }
 };
 
 // ---- epilogues -------------------------------------------------------------------------

@@ -18,6 +18,10 @@ int fc_dgrad(const float *dY, int lddy, const float *W, int Kin, int N, const fl
 int fc_wgrad_slabs(const float *X, int ldx, const float *dY, int lddy, int64_t S, int Kin, int N,
                    float *slabs, int max_slabs, int *nslabs, hipStream_t s);
 int wgrad_max_slabs(int64_t S, int Kin, int N);
+// true when the bias row is better summed on its own than folded into the product as a row of ones
+bool wgrad_bias_separately(int Kin);
+// row Kin of every slab = column sums of dY over that slab's sample rows
+int slab_bias_rows(const float *dY, int lddy, int64_t S, int Kin, int N, float *slabs, int nslabs, hipStream_t s);
 // dst[i] (+)= sum_z slabs[z][i]
 int reduce_slabs(const float *slabs, int nslabs, int64_t size, float *dst, bool accumulate, hipStream_t s);
 

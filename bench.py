@@ -35,6 +35,9 @@ WORKLOADS = {
     # the same shape through the fork's own network/loss (256-128, 5 value channels)
     "mujoco_fork": dict(D=17, A=6, E=2048, T=256, hidden=(256, 128), R=5, upstream=False, nmb=4, noptepochs=4,
                         lr=3e-4, cliprange=0.2, ent_coef=0.0, done_p=1.0 / 200),
+    # BASELINE.json configs[2]: synthetic Atari-shaped rollout, nature_cnn, Categorical(6)
+    "atari_cnn": dict(hwc=(84, 84, 4), A=6, E=256, T=128, R=1, upstream=True, nmb=4, noptepochs=4, lr=2.5e-4,
+                      cliprange=0.1, ent_coef=0.01, done_p=1.0 / 1000),
 }
 
 
@@ -62,6 +65,47 @@ def measured_traffic(workload, kernel):
     if prof.get("workload") != workload or not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
         return None
     return k["FETCH_SIZE"] + k["WRITE_SIZE"]
+
+
+def cnn_flops_per_sample(hwc, nact):
+    """nature_cnn on HxWxC: forward + weight gradients (same) + input gradients (same minus conv1)."""
+    H, W, C = hwc
+    o = lambda n, k, s: (n - k) // s + 1
+    h1, w1 = o(H, 8, 4), o(W, 8, 4)
+    h2, w2 = o(h1, 4, 2), o(w1, 4, 2)
+    h3, w3 = o(h2, 3, 1), o(w2, 3, 1)
+    conv1 = 2 * h1 * w1 * 32 * 8 * 8 * C
+    fwd = conv1 + 2 * h2 * w2 * 64 * 4 * 4 * 32 + 2 * h3 * w3 * 64 * 3 * 3 * 64 + 2 * h3 * w3 * 64 * 512 + 2 * 512 * (nact + 1)
+    return 3 * fwd - conv1
+
+
+def make_image_rollout(model, cfg, seed, device):
+    """Synthetic Atari-shaped rollout in HBM: uniform uint8 frames, Gumbel-max actions, values and
+    neglogpacs from the initial policy."""
+    from baselines_amd import hip
+    from baselines_amd.ppo2.common_functions import DeviceRollout
+    T, E, A = cfg["T"], cfg["E"], cfg["A"]
+    H, W, C = cfg["hwc"]
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    obs = torch.randint(0, 256, (T, E, H, W, C), generator=g, device=device, dtype=torch.uint8)
+    rewards = torch.randn((T, E, 1), generator=g, device=device)
+    dones = (torch.rand((T, E), generator=g, device=device) < cfg["done_p"]).to(torch.uint8)
+    last_dones = (torch.rand((E,), generator=g, device=device) < cfg["done_p"]).to(torch.uint8)
+    spec, theta = model.spec, model.arena.theta
+    ws = torch.empty(spec.forward_workspace_bytes(E), dtype=torch.uint8, device=device)
+    actions = torch.empty((T, E), dtype=torch.int32, device=device)
+    values = torch.empty((T, E, 1), device=device)
+    nlp = torch.empty((T, E), device=device)
+    for t in range(T):
+        pi, vf, _ = hip.policy_forward(spec, theta, obs[t], ws)
+        u = torch.rand((E, A), generator=g, device=device).clamp_(1e-12, 1.0)
+        a = torch.argmax(pi - torch.log(-torch.log(u)), dim=1).to(torch.int32)
+        actions[t] = a
+        values[t] = vf.reshape(E, 1)
+        nlp[t] = hip.neglogp(spec, theta, pi, a)
+    last_values = torch.randn((E, 1), generator=g, device=device)
+    return DeviceRollout(T, E, obs, actions, rewards, values, nlp, dones, last_values, last_dones)
 
 
 def make_rollout(model, cfg, seed, device):
@@ -98,7 +142,8 @@ def cpu_baseline(model, ro, cfg, budget_s=20.0):
     host = {k: getattr(ro, k).cpu().numpy() for k in ("obs", "actions", "rewards", "values", "neglogpacs", "dones",
                                                        "last_values", "last_dones")}
     params = {name: arr for (name, _, _), arr in zip(model.spec.vars, model.arena.get_list())}
-    oracle = tfgraph.TrainOracle(params, "mlp", "gaussian",
+    image = "hwc" in cfg
+    oracle = tfgraph.TrainOracle(params, "cnn" if image else "mlp", "categorical" if image else "gaussian",
                                  tfgraph.LossCfg(cfg["ent_coef"], 0.5, 0.5, cfg["upstream"]), dtype=torch.float32)
     B = N // cfg["nmb"]
     np.random.seed(0)
@@ -158,16 +203,22 @@ def main():
     from baselines_amd.ppo2 import policies
     from baselines_amd.ppo2.common_functions import Model
 
-    T, E, D, A, R = cfg["T"], cfg["E"], cfg["D"], cfg["A"], cfg["R"]
+    T, E, A, R = cfg["T"], cfg["E"], cfg["A"], cfg["R"]
+    image = "hwc" in cfg
+    D = None if image else cfg["D"]
     N = T * E
     B = N // cfg["nmb"]
     np.random.seed(1)                     # parameter init stream (ortho_init)
-    policy = policies.MlpPolicy64 if cfg["upstream"] else policies.MlpPolicy
-    model = Model(policy=policy, ob_space=spaces.Box(-np.inf, np.inf, shape=(D,)), ac_space=spaces.Box(-1, 1, shape=(A,)),
+    if image:
+        policy, ob_space, ac_space = policies.CnnPolicy, spaces.Box(0, 255, shape=cfg["hwc"], dtype=np.uint8), spaces.Discrete(A)
+    else:
+        policy = policies.MlpPolicy64 if cfg["upstream"] else policies.MlpPolicy
+        ob_space, ac_space = spaces.Box(-np.inf, np.inf, shape=(D,)), spaces.Box(-1, 1, shape=(A,))
+    model = Model(policy=policy, ob_space=ob_space, ac_space=ac_space,
                   nbatch_act=E, nbatch_train=B, nsteps=T, ent_coef=cfg["ent_coef"], vf_coef=0.5, max_grad_norm=0.5,
                   upstream_loss=cfg["upstream"], comm=comm)
     model.seed_shuffle(0)                 # same index stream on every rank
-    ro = make_rollout(model, cfg, seed=rank, device=device)
+    ro = (make_image_rollout if image else make_rollout)(model, cfg, seed=rank, device=device)
     gamma = 0.99 if R == 1 else [0.99] * R
 
     def step(events=None):
@@ -242,7 +293,14 @@ def main():
     grad_ms = float(np.mean([a.elapsed_time(b) for a, b in events["grad"]]))
 
     if rank == 0:
-        flops_mb = dense_flops_per_sample(D, cfg["hidden"], A, R) * B
+        flops_mb = (cnn_flops_per_sample(cfg["hwc"], A) if image else dense_flops_per_sample(D, cfg["hidden"], A, R)) * B
+        fused = (not image) and cfg["hidden"] == (64, 64)
+        if image:
+            shape = "Atari-shaped rollout: %dx%dx%d uint8 obs, nature_cnn Categorical(%d)" % (cfg["hwc"] + (A,))
+            which = "configs[2]"
+        else:
+            shape = "MuJoCo-shaped rollout: obs_dim=%d act_dim=%d Gaussian MLP%s" % (D, A, str(cfg["hidden"]).replace(" ", ""))
+            which = "configs[1]"
         achieved_tf = flops_mb / (grad_ms * 1e-3) / 1e12
         gae_bytes = T * E * (16 * R + 1) + E * (4 * R + 1)
         gae_gbs = gae_bytes / (gae_ms * 1e-3) / 1e9
@@ -250,17 +308,17 @@ def main():
             "metric": "PPO2 samples/sec (GAE+update)", "value": world * N * args.steps / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1] synthetic MuJoCo-shaped rollout: obs_dim=%d act_dim=%d Gaussian MLP%s "
-                                   "nenvs=%d nsteps=%d per GPU, %d minibatches x %d epochs, %s loss"
-                                   % (D, A, str(cfg["hidden"]).replace(" ", ""), E, T, cfg["nmb"], cfg["noptepochs"],
-                                      "upstream" if cfg["upstream"] else "fork"),
+            "config": {"workload": "%s synthetic %s nenvs=%d nsteps=%d per GPU, %d minibatches x %d epochs, %s loss"
+                                   % (which, shape, E, T, cfg["nmb"], cfg["noptepochs"], "upstream" if cfg["upstream"] else "fork"),
                        "samples_per_step_per_gpu": N, "nbatch_train": B,
                        "parallelism": "env-sharded dp%d, RCCL grad all-reduce (MpiAdam semantics)" % world if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "ppo_grad = mlp_fused16_kernel + fused_finalize_kernel (minibatch gather, forward, "
-                                                    "loss, backward and weight gradients on fp32 MFMA)",
+            "roofline": {"bound": "mfma",
+                         "kernel": ("ppo_grad = mlp_fused16_kernel + fused_finalize_kernel (minibatch gather, forward, loss, "
+                                    "backward and weight gradients on fp32 MFMA)") if fused else
+                                   "ppo_grad = gather + layered fp32-MFMA GEMM / implicit-GEMM conv launches + loss + slab reductions",
                          "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / MFMA_F32_PEAK_TFLOPS,
-                         "traffic": measured_traffic(args.workload, "ppo2hip::mlp_fused16_kernel<5, true>"),
+                         "traffic": measured_traffic(args.workload, "ppo2hip::mlp_fused16_kernel<5, true>") if fused else None,
                          "flops_per_launch": flops_mb, "ms_per_launch": grad_ms},
             "gae_roofline": {"bound": "hbm", "kernel": "gae_tiled_kernel", "achieved": gae_gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": gae_gbs / HBM_PEAK_GBS, "bytes_per_launch": gae_bytes,
