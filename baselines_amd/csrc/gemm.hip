@@ -26,12 +26,13 @@ int fc_dgrad(const float *dY, int lddy, const float *W, int Kin, int N, const fl
 bool wgrad_bias_separately(int Kin);
 
 static int pick_slabs(int64_t S, int64_t tiles) {
-    // enough workgroups to fill 256 CUs a few times over, at least 256 sample rows per slab
-    int64_t want = ceil_div(1024, tiles > 0 ? tiles : 1);
+    // A product with few output tiles has nothing but resident workgroups to hide its load latency with
+    // (one k-slab of loads per 16 MFMA steps): aim at eight workgroups per CU, at least 256 sample rows per slab.
+    int64_t want = ceil_div(2048, tiles > 0 ? tiles : 1);
     int64_t cap = ceil_div(S, 256);
     int64_t n = want < cap ? want : cap;
     if (n < 1) n = 1;
-    if (n > 128) n = 128;
+    if (n > 1024) n = 1024;
     return (int)n;
 }
 
@@ -97,27 +98,42 @@ int fc_wgrad_slabs(const float *X, int ldx, const float *dY, int lddy, int64_t S
     return launch_gemm(A, B, ep, Kin + 1, N, S, n, s, "fc_wgrad");
 }
 
-// 64 consecutive elements x 4 slab groups per workgroup: coalesced along the element axis,
-// the slab axis split over the four waves and finished through LDS in a fixed order.
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float *__restrict__ slabs, int nslabs, int64_t size,
-                                                           float *__restrict__ dst, int accumulate) {
-    __shared__ float part[4][64];
+// 64 consecutive elements x 16 slab groups per workgroup: coalesced along the element axis, the slab axis
+// split over sixteen waves (a handful of independent loads each) and finished through LDS in a fixed order.
+constexpr int kReduceGroups = 16;
+__global__ __launch_bounds__(64 * kReduceGroups) void reduce_slabs_kernel(const float *__restrict__ slabs, int nslabs,
+                                                                          int64_t size, float *__restrict__ dst,
+                                                                          int accumulate) {
+    __shared__ float part[kReduceGroups][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (i < size)
-        for (int z = grp; z < nslabs; z += 4) s += slabs[(int64_t)z * size + i];
+    if (i < size) {
+        constexpr int U = 8;
+        for (int z0 = grp; z0 < nslabs; z0 += kReduceGroups * U) {
+            float x[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int z = z0 + u * kReduceGroups;
+                x[u] = z < nslabs ? slabs[(int64_t)z * size + i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) s += x[u];
+        }
+    }
     part[grp][lane] = s;
     __syncthreads();
     if (grp == 0 && i < size) {
-        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < kReduceGroups; q++) t += part[q][lane];
         dst[i] = accumulate ? dst[i] + t : t;
     }
 }
 
 int reduce_slabs(const float *slabs, int nslabs, int64_t size, float *dst, bool accumulate, hipStream_t s) {
     if (size <= 0) return 0;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(size, 64)), dim3(256), 0, s, slabs, nslabs,
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(size, 64)), dim3(64 * kReduceGroups), 0, s, slabs, nslabs,
                        size, dst, accumulate ? 1 : 0);
     return check_launch("reduce_slabs");
 }
