@@ -38,6 +38,9 @@ WORKLOADS = {
     # BASELINE.json configs[2]: synthetic Atari-shaped rollout, nature_cnn, Categorical(6)
     "atari_cnn": dict(hwc=(84, 84, 4), A=6, E=256, T=128, R=1, upstream=True, nmb=4, noptepochs=4, lr=2.5e-4,
                       cliprange=0.1, ent_coef=0.01, done_p=1.0 / 1000),
+    # BASELINE.json configs[4]: cnn_lstm, env-sequence minibatches of E/4 envs x T steps
+    "atari_lstm": dict(hwc=(84, 84, 4), A=6, E=512, T=128, R=1, upstream=True, nmb=4, noptepochs=4, lr=2.5e-4,
+                       cliprange=0.1, ent_coef=0.01, done_p=1.0 / 1000, nlstm=256),
 }
 
 
@@ -67,15 +70,19 @@ def measured_traffic(workload, kernel):
     return k["FETCH_SIZE"] + k["WRITE_SIZE"]
 
 
-def cnn_flops_per_sample(hwc, nact):
-    """nature_cnn on HxWxC: forward + weight gradients (same) + input gradients (same minus conv1)."""
+def cnn_flops_per_sample(hwc, nact, nlstm=0):
+    """nature_cnn on HxWxC (+ LSTM(nlstm) on its 512 features): forward + weight gradients (same) +
+    input gradients (same minus conv1)."""
     H, W, C = hwc
     o = lambda n, k, s: (n - k) // s + 1
     h1, w1 = o(H, 8, 4), o(W, 8, 4)
     h2, w2 = o(h1, 4, 2), o(w1, 4, 2)
     h3, w3 = o(h2, 3, 1), o(w2, 3, 1)
     conv1 = 2 * h1 * w1 * 32 * 8 * 8 * C
-    fwd = conv1 + 2 * h2 * w2 * 64 * 4 * 4 * 32 + 2 * h3 * w3 * 64 * 3 * 3 * 64 + 2 * h3 * w3 * 64 * 512 + 2 * 512 * (nact + 1)
+    feat = nlstm if nlstm else 512
+    fwd = conv1 + 2 * h2 * w2 * 64 * 4 * 4 * 32 + 2 * h3 * w3 * 64 * 3 * 3 * 64 + 2 * h3 * w3 * 64 * 512 + 2 * feat * (nact + 1)
+    if nlstm:
+        fwd += 2 * (512 + nlstm) * 4 * nlstm
     return 3 * fwd - conv1
 
 
@@ -97,15 +104,21 @@ def make_image_rollout(model, cfg, seed, device):
     actions = torch.empty((T, E), dtype=torch.int32, device=device)
     values = torch.empty((T, E, 1), device=device)
     nlp = torch.empty((T, E), device=device)
+    nlstm = cfg.get("nlstm", 0)
+    states0 = torch.zeros((E, 2 * nlstm), device=device) if nlstm else None
+    state = states0
     for t in range(T):
-        pi, vf, _ = hip.policy_forward(spec, theta, obs[t], ws)
+        if nlstm:
+            pi, vf, state = hip.policy_forward(spec, theta, obs[t], ws, masks=dones[t], states=state)
+        else:
+            pi, vf, _ = hip.policy_forward(spec, theta, obs[t], ws)
         u = torch.rand((E, A), generator=g, device=device).clamp_(1e-12, 1.0)
         a = torch.argmax(pi - torch.log(-torch.log(u)), dim=1).to(torch.int32)
         actions[t] = a
         values[t] = vf.reshape(E, 1)
         nlp[t] = hip.neglogp(spec, theta, pi, a)
     last_values = torch.randn((E, 1), generator=g, device=device)
-    return DeviceRollout(T, E, obs, actions, rewards, values, nlp, dones, last_values, last_dones)
+    return DeviceRollout(T, E, obs, actions, rewards, values, nlp, dones, last_values, last_dones, states=states0)
 
 
 def make_rollout(model, cfg, seed, device):
@@ -210,7 +223,8 @@ def main():
     B = N // cfg["nmb"]
     np.random.seed(1)                     # parameter init stream (ortho_init)
     if image:
-        policy, ob_space, ac_space = policies.CnnPolicy, spaces.Box(0, 255, shape=cfg["hwc"], dtype=np.uint8), spaces.Discrete(A)
+        policy = policies.LstmPolicy if cfg.get("nlstm") else policies.CnnPolicy
+        ob_space, ac_space = spaces.Box(0, 255, shape=cfg["hwc"], dtype=np.uint8), spaces.Discrete(A)
     else:
         policy = policies.MlpPolicy64 if cfg["upstream"] else policies.MlpPolicy
         ob_space, ac_space = spaces.Box(-np.inf, np.inf, shape=(D,)), spaces.Box(-1, 1, shape=(A,))
@@ -293,11 +307,12 @@ def main():
     grad_ms = float(np.mean([a.elapsed_time(b) for a, b in events["grad"]]))
 
     if rank == 0:
-        flops_mb = (cnn_flops_per_sample(cfg["hwc"], A) if image else dense_flops_per_sample(D, cfg["hidden"], A, R)) * B
+        flops_mb = (cnn_flops_per_sample(cfg["hwc"], A, cfg.get("nlstm", 0)) if image else dense_flops_per_sample(D, cfg["hidden"], A, R)) * B
         fused = (not image) and cfg["hidden"] == (64, 64)
         if image:
-            shape = "Atari-shaped rollout: %dx%dx%d uint8 obs, nature_cnn Categorical(%d)" % (cfg["hwc"] + (A,))
-            which = "configs[2]"
+            shape = "Atari-shaped rollout: %dx%dx%d uint8 obs, nature_cnn%s Categorical(%d)" % (
+                cfg["hwc"] + (" + LSTM(%d), env-sequence minibatches," % cfg["nlstm"] if cfg.get("nlstm") else "", A))
+            which = "configs[4]" if cfg.get("nlstm") else "configs[2]"
         else:
             shape = "MuJoCo-shaped rollout: obs_dim=%d act_dim=%d Gaussian MLP%s" % (D, A, str(cfg["hidden"]).replace(" ", ""))
             which = "configs[1]"
