@@ -221,6 +221,33 @@ __global__ void discount_kernel(const float *__restrict__ rewards, const uint8_t
     }
 }
 
+// Y[t] = X[t] + gamma*Y[t+1]*(1 - starts[t+1]) down one column: scipy's lfilter([1],[1,-gamma]) on the
+// reversed input (baselines/common/math_util.py:23, float64 out, no flags) and discount_with_boundaries
+// (baselines/common/math_util.py:63-73, where Y has X's dtype, so a float32 Y carries the ROUNDED value).
+template <class X, class Y, int UNROLL>
+__global__ void discount_axis0_kernel(const X *__restrict__ x, const uint8_t *__restrict__ starts, double gamma,
+                                      int T, int64_t C, Y *__restrict__ out) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double y = 0.0;
+    auto step = [&](int t, X xv) {
+        // the carry is zero at t = T-1, so starts[T] is never needed
+        const double keep = (starts && t + 1 < T) ? 1.0 - (double)(starts[t + 1] != 0) : 1.0;
+        const Y stored = (Y)__dadd_rn((double)xv, __dmul_rn(__dmul_rn(gamma, y), keep));
+        out[(int64_t)t * C + c] = stored;
+        y = (double)stored;
+    };
+    int t = T - 1;
+    for (; t - (UNROLL - 1) >= 0; t -= UNROLL) {
+        X xv[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) xv[u] = x[(int64_t)(t - u) * C + c];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) step(t - u, xv[u]);
+    }
+    for (; t >= 0; t--) step(t, x[(int64_t)t * C + c]);
+}
+
 // [T, E, row] -> [E, T, row].  Large rows: one workgroup streams one row.
 template <class W>
 __global__ void sf01_bigrow_kernel(const W *__restrict__ src, int T, int E, int64_t row_words,
@@ -294,6 +321,27 @@ extern "C" int ppo2hip_discount_with_dones_f32(const float *rewards, const uint8
     hipLaunchKernelGGL(discount_kernel<8>, dim3((unsigned)ceil_div(E, block)), dim3(block), 0,
                        (hipStream_t)stream, rewards, dones, last_values, gamma, T, E, out);
     return check_launch("discount_kernel");
+}
+
+extern "C" int ppo2hip_discount(const void *x, int x_f64, const uint8_t *starts, double gamma, int T, int64_t C,
+                                void *out, int out_f64, void *stream) {
+    PPO2HIP_REQUIRE(T >= 0 && C >= 0, "discount: bad shape T=%d C=%lld", T, (long long)C);
+    PPO2HIP_REQUIRE(out_f64 || !x_f64, "discount: float64 input needs float64 output");
+    if (T == 0 || C == 0) return PPO2HIP_OK;
+    PPO2HIP_REQUIRE(x && out, "discount: null pointer");
+    const int block = C <= 65536 ? 64 : 256;
+    const dim3 grid((unsigned)ceil_div(C, block));
+    hipStream_t s = (hipStream_t)stream;
+    if (x_f64)
+        hipLaunchKernelGGL((discount_axis0_kernel<double, double, 8>), grid, dim3(block), 0, s, (const double *)x, starts,
+                           gamma, T, C, (double *)out);
+    else if (out_f64)
+        hipLaunchKernelGGL((discount_axis0_kernel<float, double, 8>), grid, dim3(block), 0, s, (const float *)x, starts,
+                           gamma, T, C, (double *)out);
+    else
+        hipLaunchKernelGGL((discount_axis0_kernel<float, float, 8>), grid, dim3(block), 0, s, (const float *)x, starts,
+                           gamma, T, C, (float *)out);
+    return check_launch("discount_axis0_kernel");
 }
 
 extern "C" int ppo2hip_sf01(const void *src, int T, int E, int64_t row_bytes, void *dst, void *stream) {

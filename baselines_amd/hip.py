@@ -80,6 +80,30 @@ def discount_with_dones(rewards, dones, last_values, gamma):
     return out
 
 
+def discount(x, gamma, starts=None, out_dtype=None):
+    """Discounted sums along axis 0 of a device tensor [T, ...] (float32 or float64).  Without
+    ``starts`` the output is float64 (what scipy's lfilter returns); with episode-start flags
+    [T] it is ``x``'s dtype unless ``out_dtype`` says otherwise."""
+    if not isinstance(x, torch.Tensor) or not x.is_cuda or not x.is_contiguous() or x.dim() < 1:
+        raise ValueError("x must be a contiguous device tensor with at least one dim")
+    if x.dtype not in (torch.float32, torch.float64):
+        raise TypeError("x must be float32 or float64")
+    T = x.shape[0]
+    C = x.numel() // T if T else 0
+    if out_dtype is None:
+        out_dtype = torch.float64 if starts is None else x.dtype
+    if out_dtype not in (torch.float32, torch.float64) or (x.dtype == torch.float64 and out_dtype != torch.float64):
+        raise TypeError("out_dtype must be float64, or float32 for float32 input")
+    if starts is not None:
+        starts = _dev(_as_u8(starts), torch.uint8, "starts")
+        if starts.numel() != T:
+            raise ValueError("starts must have one flag per time step")
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(lib.ppo2hip_discount(_ptr(x), int(x.dtype == torch.float64), _ptr(starts), float(gamma), T, C, _ptr(out),
+                               int(out_dtype == torch.float64), _stream()), "discount")
+    return out
+
+
 def sf01(arr):
     """[T, E, ...] -> [E*T, ...] on device."""
     if not arr.is_cuda or not arr.is_contiguous() or arr.dim() < 2:
@@ -92,6 +116,97 @@ def sf01(arr):
     out = torch.empty((T * E,) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
     check(lib.ppo2hip_sf01(_ptr(src), T, E, row_bytes, _ptr(out), _stream()), "sf01")
     return out.view(arr.dtype) if arr.dtype == torch.bool else out
+
+
+# --------------------------------------------------------------------------------------
+# env-wrapper filters
+# --------------------------------------------------------------------------------------
+
+def _float_dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or not t.is_contiguous():
+        raise TypeError("%s must be a contiguous device tensor" % name)
+    if t.dtype not in (torch.float32, torch.float64):
+        raise TypeError("%s must be float32 or float64" % name)
+    return t
+
+
+def rms_state(d, epsilon=1e-4, device="cuda"):
+    """Device statistics of one RunningMeanStd: double[3*d] = mean 0, var 1, count epsilon."""
+    st = torch.empty(3 * int(d), dtype=torch.float64, device=device)
+    st[:d] = 0.0
+    st[d:2 * d] = 1.0
+    st[2 * d:] = float(epsilon)
+    return st
+
+
+def rms_update(state, x, workspace=None):
+    """Merge the batch ``x`` [n, ...] into ``state`` (RunningMeanStd.update)."""
+    x = _float_dev(x, "x")
+    n = x.shape[0] if x.dim() else 0
+    d = state.numel() // 3
+    if x.numel() != n * d:
+        raise ValueError("x must be [n, %d]" % d)
+    need = lib.ppo2hip_rms_workspace_bytes(n, d)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    check(lib.ppo2hip_rms_update(_ptr(x), int(x.dtype == torch.float64), n, d, _ptr(_dev(state, torch.float64, "state")),
+                                 _ptr(workspace), workspace.numel(), _stream()), "rms_update")
+    return workspace
+
+
+def normalize_clip(x, state, epsilon, clip, center=True, out_dtype=torch.float32):
+    """clip((x - mean) / sqrt(var + epsilon), -clip, clip) with the statistics in ``state``."""
+    x = _float_dev(x, "x")
+    d = state.numel() // 3
+    n = x.numel() // d if d else 0
+    if x.numel() != n * d:
+        raise ValueError("x must be [n, %d]" % d)
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean, var = state[:d], state[d:2 * d]
+    check(lib.ppo2hip_normalize_clip(_ptr(x), int(x.dtype == torch.float64), n, d, _ptr(mean) if center else None,
+                                     _ptr(var), float(epsilon), float(clip), _ptr(out), int(out_dtype == torch.float64),
+                                     _stream()), "normalize_clip")
+    return out
+
+
+def vecnorm_returns(rews, ret, state, gamma, epsilon, clip, out_dtype=torch.float32, workspace=None):
+    """ret = ret*gamma + rews; update ``state`` with ret; return clip(rews / sqrt(var + epsilon))."""
+    rews = _float_dev(rews, "rews")
+    E = rews.numel()
+    _dev(ret, torch.float64, "ret")
+    if ret.numel() != E:
+        raise ValueError("ret must hold one float64 per env")
+    if state is None:
+        out_dtype = rews.dtype
+    need = lib.ppo2hip_rms_workspace_bytes(E, 1)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=rews.device)
+    out = torch.empty(rews.shape, dtype=out_dtype, device=rews.device)
+    check(lib.ppo2hip_vecnorm_returns(_ptr(rews), int(rews.dtype == torch.float64), E, float(gamma), _ptr(ret), _ptr(state),
+                                      float(epsilon), float(clip), _ptr(out), int(out_dtype == torch.float64),
+                                      _ptr(workspace), workspace.numel(), _stream()), "vecnorm_returns")
+    return out
+
+
+def frame_stack(stacked, obs, news=None):
+    """Roll ``stacked`` [E, ..., nstack*c] in place as np.roll(shift=-1) on the last axis does and
+    write ``obs`` [E, ..., c] into the last c places."""
+    if not (isinstance(stacked, torch.Tensor) and stacked.is_cuda and stacked.is_contiguous() and obs.is_cuda
+            and obs.is_contiguous() and stacked.dtype == obs.dtype and stacked.dim() >= 2 and obs.dim() == stacked.dim()):
+        raise TypeError("stacked and obs must be contiguous device tensors of one dtype and rank")
+    if stacked.element_size() not in (1, 4):
+        raise TypeError("elements of 1 or 4 bytes")
+    E, c, sc = stacked.shape[0], obs.shape[-1], stacked.shape[-1]
+    if obs.shape[:-1] != stacked.shape[:-1] or c == 0 or sc % c:
+        raise ValueError("obs %s does not stack into %s" % (tuple(obs.shape), tuple(stacked.shape)))
+    pixels = stacked.numel() // (E * sc) if E else 0
+    if news is not None:
+        news = _dev(_as_u8(news), torch.uint8, "news")
+        if news.numel() != E:
+            raise ValueError("news must hold one flag per env")
+    check(lib.ppo2hip_frame_stack(_ptr(stacked), _ptr(obs), _ptr(news), E, pixels, c, sc // c, stacked.element_size(),
+                                  _stream()), "frame_stack")
+    return stacked
 
 
 # --------------------------------------------------------------------------------------

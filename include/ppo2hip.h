@@ -61,9 +61,56 @@ int ppo2hip_discount_with_dones_f32(const float *rewards, const uint8_t *dones,
                                     const float *last_values, double gamma, int T, int E,
                                     float *out, void *stream);
 
+/* Discounted sums along axis 0: Y[t] = X[t] + gamma * Y[t+1] * (1 - starts[t+1]).
+ * Replaces math_util.discount, baselines/common/math_util.py:5-23 (scipy's lfilter in float64:
+ * starts NULL, out_f64 = 1), and discount_with_boundaries, baselines/common/math_util.py:63-73
+ * (`Y = np.zeros_like(X)`: out has X's dtype and a float32 Y carries the rounded value).
+ *   x : float32 or float64 (x_f64 != 0) [T, C]     starts : uint8 [T] episode-start flags or NULL
+ *   out : float64 (out_f64 != 0) or float32 [T, C]; float64 input needs float64 output */
+int ppo2hip_discount(const void *x, int x_f64, const uint8_t *starts, double gamma, int T, int64_t C,
+                     void *out, int out_f64, void *stream);
+
 /* sf01: [T, E, row] -> [E*T, row] (swap and flatten axes 0 and 1),
  * baselines/ppo2/common_functions.py:347-352.  row_bytes = bytes of one trailing row. */
 int ppo2hip_sf01(const void *src, int T, int E, int64_t row_bytes, void *dst, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Env-wrapper filters (the step before the rollout scan)
+ * ---------------------------------------------------------------------- */
+
+/* RunningMeanStd.update, baselines/common/running_mean_std.py:9-29: batch mean / variance over
+ * axis 0 merged into the running statistics by the parallel-variance rule.
+ *   x : float32 or float64 (x_f64 != 0) [n, d], n >= 1
+ *   state : DEVICE double[3*d] = mean[d], var[d], count[d] (the reference's scalar count, kept
+ *           once per column); initialise to 0, 1, epsilon as RunningMeanStd.__init__ does (:4-7)
+ *   workspace : device, ppo2hip_rms_workspace_bytes(n, d) bytes */
+size_t ppo2hip_rms_workspace_bytes(int64_t n, int64_t d);
+int ppo2hip_rms_update(const void *x, int x_f64, int64_t n, int64_t d, double *state, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
+/* clip((x - mean) / sqrt(var + epsilon), -clip, clip), the filter of VecNormalize._obfilt,
+ * baselines/common/vec_env/vec_normalize.py:37; mean NULL = no centring (the reward filter, :31).
+ *   x [n, d] float32/float64; mean, var : device double[d]; out [n, d] float32 or float64 */
+int ppo2hip_normalize_clip(const void *x, int x_f64, int64_t n, int64_t d, const double *mean,
+                           const double *var, double epsilon, double clip, void *out, int out_f64,
+                           void *stream);
+
+/* The reward half of VecNormalize.step_wait, baselines/common/vec_env/vec_normalize.py:27-31:
+ * ret = ret*gamma + rews; ret_rms.update(ret); out = clip(rews / sqrt(ret_rms.var + epsilon)).
+ *   rews [E]; ret : device double[E] in/out; state : device double[3] (mean, var, count) or NULL
+ *   (ret=False: only ret is advanced, out = rews); workspace: ppo2hip_rms_workspace_bytes(E, 1) */
+int ppo2hip_vecnorm_returns(const void *rews, int rews_f64, int64_t E, double gamma, double *ret,
+                            double *state, double epsilon, double clip, void *out, int out_f64,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* VecFrameStack.step_wait, baselines/common/vec_env/vec_frame_stack.py:19-26, in place:
+ * every pixel's nstack*channels values move ONE element towards the front (np.roll(shift=-1) on
+ * the last axis: one frame when channels == 1, and the reference's behaviour as it stands for
+ * channels > 1), envs flagged in `news` (uint8 [E], NULL = none) restart from zeros, `obs` fills
+ * the last `channels` places.
+ *   stacked [E, pixels, nstack*channels], obs [E, pixels, channels]; elem_bytes 1 (uint8) or 4 */
+int ppo2hip_frame_stack(void *stacked, const void *obs, const uint8_t *news, int64_t E, int64_t pixels,
+                        int channels, int nstack, int elem_bytes, void *stream);
 
 /* ------------------------------------------------------------------------
  * Advantage post-processing

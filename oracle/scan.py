@@ -65,6 +65,50 @@ def gae_single_env(rew, vpred, new, nextvpred, gamma, lam):
     return adv, adv + vpred
 
 
+def gae_single_env_f64(rew, vpred, new, nextvpred, gamma, lam):
+    """``baselines/ppo1/pposgd_simple.py:64-78`` with the scalar promotion of the NumPy the
+    reference was written for: a Python-float ``gamma`` times a float32 ELEMENT gives float64
+    there (value-based casting), so ``delta`` and the carry are float64 and only the store into
+    ``gaelam`` rounds.  NumPy >= 2 keeps such products in float32; ``gae_single_env`` above
+    follows whichever NumPy runs it."""
+    new = np.append(np.asarray(new), 0)
+    vpred_ext = np.append(np.asarray(vpred, np.float32), np.float32(nextvpred)).astype(np.float64)
+    rew = np.asarray(rew, np.float32).astype(np.float64)
+    T = len(rew)
+    adv = np.empty(T, 'float32')
+    lastgaelam = 0.0
+    for t in reversed(range(T)):
+        nonterminal = float(1 - new[t + 1])
+        delta = rew[t] + gamma * vpred_ext[t + 1] * nonterminal - vpred_ext[t]
+        adv[t] = lastgaelam = delta + gamma * lam * nonterminal * lastgaelam
+    return adv, adv + np.asarray(vpred, np.float32)
+
+
+def discount(x, gamma):
+    """``baselines/common/math_util.py:5-23``: ``scipy.signal.lfilter([1], [1, -gamma], x[::-1],
+    axis=0)[::-1]``.  lfilter's transposed direct form II with these coefficients is
+    ``y[n] = x[n] + z``, ``z = gamma * y[n]`` in float64, i.e. a reverse scan over axis 0."""
+    x = np.asarray(x)
+    y = np.zeros(x.shape, np.float64)
+    carry = np.zeros(x.shape[1:], np.float64)
+    for t in reversed(range(x.shape[0])):
+        carry = x[t].astype(np.float64) + gamma * carry
+        y[t] = carry
+    return y
+
+
+def discount_with_boundaries_legacy(X, New, gamma):
+    """``baselines/common/math_util.py:63-73`` with float64 scalar arithmetic and a store in
+    ``X``'s dtype each step (``Y = np.zeros_like(X)``), the carry being the stored value."""
+    X = np.asarray(X)
+    Y = np.zeros_like(X)
+    T = X.shape[0]
+    Y[T - 1] = X[T - 1]
+    for t in range(T - 2, -1, -1):
+        Y[t] = X[t].astype(np.float64) + gamma * Y[t + 1].astype(np.float64) * float(1 - New[t + 1])
+    return Y
+
+
 def discount_with_dones(rewards, dones, gamma):
     """``baselines/a2c/utils.py:154-160`` — Python-float (f64) reverse scan."""
     discounted = []

@@ -158,3 +158,52 @@ def test_compose_permutations(hip):
     np.testing.assert_array_equal(out.cpu().numpy(), prev[sig])
     with pytest.raises(ValueError):
         hip.compose(torch.from_numpy(prev).cuda(), torch.from_numpy(sig[:10]).cuda(), out)
+
+
+@pytest.mark.parametrize("shape,dtype", [((1,), np.float32), ((2048,), np.float32), ((129, 5), np.float64), ((40, 70, 3), np.float32)])
+def test_math_util_discount(hip, shape, dtype):
+    from baselines_amd.common import math_util
+    x = np.random.RandomState(sum(shape)).randn(*shape).astype(dtype)
+    got = math_util.discount(x, 0.97)
+    assert got.dtype == np.float64 and got.shape == x.shape
+    np.testing.assert_array_equal(got, scan.discount(x, 0.97))
+    assert math_util.discount(np.zeros((0, 3), np.float32), 0.9).shape == (0, 3)
+    with pytest.raises(TypeError):
+        hip.discount(dev(x.astype(np.float64)), 0.9, out_dtype=torch.float32)
+
+
+def test_math_util_discount_with_boundaries(hip, golden):
+    from baselines_amd.common import math_util
+    y = math_util.discount_with_boundaries(golden["dwb_x"], golden["dwb_starts"], 0.9)
+    assert y.dtype == golden["dwb_x"].dtype
+    np.testing.assert_allclose(y, golden["dwb_y"], rtol=0, atol=1e-6)     # fixture made with weak-scalar NumPy
+    rng = np.random.RandomState(4)
+    for dtype in (np.float32, np.float64):
+        X = rng.randn(300, 6).astype(dtype)
+        New = rng.rand(300) < 0.1
+        np.testing.assert_array_equal(math_util.discount_with_boundaries(X, New, 0.95),
+                                      scan.discount_with_boundaries_legacy(X, New, 0.95))
+
+
+def test_add_vtarg_and_adv(hip, golden):
+    from baselines_amd.ppo1.pposgd_simple import add_vtarg_and_adv
+    from baselines_amd.trpo_mpi import trpo_mpi
+    assert trpo_mpi.add_vtarg_and_adv is add_vtarg_and_adv
+    for name in ["a", "b", "c"]:
+        g = lambda k: golden["gae1_%s_%s" % (name, k)]
+        nextv = g("last_value") * (1 - bool(g("last_done")))
+        seg = dict(rew=g("rew"), vpred=g("vpred"), new=g("new"), nextvpred=nextv)
+        add_vtarg_and_adv(seg, 0.99, 0.95)
+        a64, r64 = scan.gae_single_env_f64(g("rew"), g("vpred"), g("new"), nextv, 0.99, 0.95)
+        np.testing.assert_array_equal(seg["adv"], a64)
+        np.testing.assert_array_equal(seg["tdlamret"], r64)
+        np.testing.assert_allclose(seg["adv"], g("adv"), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(seg["tdlamret"], g("tdlamret"), rtol=0, atol=1e-6)
+    rng = np.random.RandomState(8)
+    T = 2048                                                     # ppo1's default horizon
+    seg = dict(rew=rng.randn(T).astype(np.float32), vpred=rng.randn(T).astype(np.float32),
+               new=(rng.rand(T) < 0.01).astype(np.int32), nextvpred=np.float32(0.3))
+    add_vtarg_and_adv(seg, 0.99, 0.95)
+    a64, r64 = scan.gae_single_env_f64(seg["rew"], seg["vpred"], seg["new"], seg["nextvpred"], 0.99, 0.95)
+    np.testing.assert_array_equal(seg["adv"], a64)
+    np.testing.assert_array_equal(seg["tdlamret"], r64)

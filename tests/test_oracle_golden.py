@@ -120,3 +120,35 @@ def test_ortho_init_matches_reference(golden):
                                ("fc_64_2", (64, 2), 0.01), ("conv_8_8_4_32", (8, 8, 4, 32), np.sqrt(2)),
                                ("fc_64_1", (64, 1), 1.0)]:
         np.testing.assert_array_equal(ortho_init(shape, scale), golden["ortho_" + name])
+
+
+def test_single_env_gae_float64_promotion(golden):
+    """The [T,1,1] case of the rollout scan IS ppo1's segment scan under value-based scalar promotion
+    (float64 carry); the fixtures, made under a NumPy with weak Python scalars, lie within 1e-6."""
+    for name in ["a", "b", "c"]:
+        g = lambda k: golden["gae1_%s_%s" % (name, k)]
+        rew, vpred, new = g("rew"), g("vpred"), g("new")
+        T = len(rew)
+        nextv = g("last_value") * (1 - bool(g("last_done")))
+        a64, r64 = scan.gae_single_env_f64(rew, vpred, new, nextv, 0.99, 0.95)
+        np.testing.assert_allclose(a64, g("adv"), rtol=0, atol=1e-6)
+        advs, rets = scan.gae(rew.reshape(T, 1, 1), vpred.reshape(T, 1, 1), new.reshape(T, 1).astype(bool),
+                              np.array([[nextv]], np.float32), np.array([False]), 0.99, 0.95)
+        np.testing.assert_array_equal(advs.ravel(), a64)
+        np.testing.assert_array_equal(rets.ravel(), r64)
+
+
+@pytest.mark.parametrize("shape,dtype", [((1,), np.float32), ((50,), np.float32), ((33, 4), np.float64), ((7, 2, 3), np.float32)])
+def test_discount_is_scipy_lfilter(shape, dtype):
+    """math_util.discount is one scipy call; the restatement must reproduce it bit for bit."""
+    import scipy.signal
+    x = np.random.RandomState(len(shape)).randn(*shape).astype(dtype)
+    ref = scipy.signal.lfilter([1], [1, -0.97], x[::-1], axis=0)[::-1]
+    got = scan.discount(x, 0.97)
+    assert got.dtype == ref.dtype == np.float64
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_discount_with_boundaries_legacy_matches_kat(golden):
+    y = scan.discount_with_boundaries_legacy(golden["dwb_x"], golden["dwb_starts"], 0.9)
+    np.testing.assert_allclose(y, golden["dwb_y"], rtol=0, atol=1e-6)
