@@ -6,7 +6,7 @@ resolve, importing this module raises.
 import ctypes
 import os
 from ctypes import (POINTER, Structure, c_char, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t,
-                    c_uint32, c_void_p)
+                    c_uint32, c_uint64, c_void_p)
 
 import torch  # noqa: F401  (loads the process's HIP runtime before ours resolves against it)
 
@@ -58,6 +58,8 @@ _SIGS = {
     "ppo2hip_vecnorm_returns": (c_int, [_P, c_int, c_int64, c_double, _P, _P, c_double, c_double, _P, c_int, _P,
                                         c_size_t, _P]),
     "ppo2hip_frame_stack": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, _P]),
+    "ppo2hip_sample_actions": (c_int, [POINTER(PolicyDesc), _P, _P, c_int64, c_uint64, c_uint64, c_int, _P, _P, _P, _P]),
+    "ppo2hip_done_bootstrap": (c_int, [_P, _P, _P, POINTER(c_double), c_int64, c_int, _P]),
     "ppo2hip_discount": (c_int, [_P, c_int, _P, c_double, c_int, c_int64, _P, c_int, _P]),
     "ppo2hip_sf01": (c_int, [_P, c_int, c_int, c_int64, _P, _P]),
     "ppo2hip_compute_advs_workspace_bytes": (c_size_t, [c_int64, c_int]),

@@ -6,6 +6,10 @@ namespace ppo2hip {
 
 enum Act { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };
 
+constexpr int kMaxR = 8;                       // value / reward channels a scan or bootstrap handles
+struct GammaVec { double g[kMaxR]; };          // per-channel discount, passed by value to kernels
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+
 // ---- dense layers on the fp32 MFMA GEMM (gemm.hip) -------------------------------------
 // Y[M,N] = act(X[M,K] W[K,N] + b)      (accumulate: Y += X W (+ b), act must be ACT_NONE)
 int fc_forward(const float *X, int ldx, const float *W, const float *b, float *Y, int ldy, int M, int N,
@@ -78,6 +82,10 @@ int loss_partial_blocks(int64_t B);
 int ppo_loss_backward(const LossArgs &a, hipStream_t s);
 int neglogp_rows(int dist, int ac_dim, const float *pi, const float *logstd, const void *actions, int64_t B,
                  float *out, hipStream_t s);
+
+// actions and their neglogp drawn from pi with counter-based noise named by (seed, step)  (sample.hip)
+int sample_rows(int dist, int ac_dim, const float *pi, const float *logstd, int64_t B, uint64_t seed, uint64_t step,
+                int deterministic, void *actions, float *neglogp, float *noise_out, hipStream_t s);
 
 int loss_final(const double *partial, int nblocks, int A_gaussian, double inv_count, float *losses, float *dlogstd,
                hipStream_t s);

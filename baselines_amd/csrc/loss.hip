@@ -11,7 +11,6 @@ namespace ppo2hip {
 constexpr int kLossBlock = 256;
 constexpr int kMaxAc = 64;
 constexpr int kPartialStride = 8 + kMaxAc;   // doubles per block: 5 loss sums (+3 pad) + dlogstd
-constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 
 int loss_partial_blocks(int64_t B) {
     int64_t n = ceil_div(B, kLossBlock);

@@ -635,6 +635,19 @@ extern "C" int ppo2hip_neglogp(const ppo2hip_policy_desc *desc, const float *par
     return neglogp_rows(desc->dist, desc->ac_dim, pi, logstd, actions, B, neglogp, (hipStream_t)stream);
 }
 
+extern "C" int ppo2hip_sample_actions(const ppo2hip_policy_desc *desc, const float *params, const float *pi, int64_t B,
+                                      uint64_t seed, uint64_t step, int deterministic, void *actions, float *neglogp,
+                                      float *noise_out, void *stream) {
+    PPO2HIP_REQUIRE(desc && params && pi && actions && neglogp && B >= 0, "sample_actions: bad argument");
+    PPO2HIP_REQUIRE(B <= 0xffffffffll, "sample_actions: more than 2^32 rows");
+    Layout L;
+    int rc = build_layout(*desc, L);
+    if (rc) return rc;
+    const float *logstd = desc->dist == PPO2HIP_DIST_GAUSSIAN ? params + L.off("logstd") : nullptr;
+    return sample_rows(desc->dist, desc->ac_dim, pi, logstd, B, seed, step, deterministic, actions, neglogp, noise_out,
+                       (hipStream_t)stream);
+}
+
 extern "C" int ppo2hip_ppo_grad(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss, const float *params,
                                 const ppo2hip_rollout *rollout, const int32_t *idx, int64_t B,
                                 const int32_t *mb_envs, int32_t nsteps_mb, const double *stats, float cliprange,

@@ -1,7 +1,7 @@
 // Reverse scans over the time-major rollout: GAE/returns, A2C discounted returns,
 // and the sf01 flatten.  HBM-bound: one lane per (env, channel) column, time walked
 // backwards, every access coalesced along the env axis.
-#include "common.hpp"
+#include "kernels.hpp"
 
 // The float64 carry of the scans must round exactly as NumPy's separate multiply and add
 // do, so no operation in this file may be contracted into an fma: the Makefile builds this
@@ -9,8 +9,6 @@
 
 namespace ppo2hip {
 
-constexpr int kMaxR = 8;
-struct GammaVec { double g[kMaxR]; };
 
 // Arithmetic of baselines/ppo2/common_functions.py:325-328 in the reference's evaluation
 // order, with explicit round-to-nearest double ops so the compiler cannot contract

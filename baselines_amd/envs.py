@@ -88,3 +88,58 @@ class SyntheticVecEnv:
 
     def close(self):
         pass
+
+
+class DevicePointVecEnv:
+    """`nenvs` point masses simulated in HBM (torch tensors): the observation is the position
+    x in R^dim, an action moves it by 0.1*clip(a, -1, 1), the reward is -|x|^2 and an episode lasts
+    `horizon` steps before the point is put back at a random place.  ``device_resident`` tells the
+    runner that reset / step speak device tensors, so a whole rollout runs without leaving the GPU.
+    Env side of the boundary: a test and benchmark fixture, not part of the update path."""
+
+    device_resident = True
+
+    def __init__(self, nenvs, dim=2, horizon=20, seed=0, reward_columns=None):
+        import torch
+        self.torch = torch
+        self.num_envs, self.dim, self.horizon = nenvs, dim, horizon
+        self.observation_space = Box(-np.inf, np.inf, shape=(dim,), dtype=np.float32)
+        self.action_space = Box(-1.0, 1.0, shape=(dim,), dtype=np.float32)
+        self.reward_columns = reward_columns
+        self.gen = torch.Generator(device="cuda")
+        self.gen.manual_seed(seed)
+        self.x = torch.zeros((nenvs, dim), device="cuda")
+        self.age = torch.zeros(nenvs, dtype=torch.int32, device="cuda")
+        self.ep_ret = torch.zeros(nenvs, device="cuda")
+        self.finished_returns = []          # device tensors of finished episodes' returns, one per step
+
+    def reset(self):
+        t = self.torch
+        self.x = t.randn((self.num_envs, self.dim), device="cuda", generator=self.gen)
+        self.age.zero_()
+        self.ep_ret.zero_()
+        return self.x.clone()
+
+    def step(self, actions):
+        t = self.torch
+        self.x = self.x + 0.1 * actions.reshape(self.num_envs, self.dim).clamp(-1.0, 1.0)
+        rew = -(self.x * self.x).sum(dim=1)
+        self.age += 1
+        self.ep_ret += rew
+        dones = self.age >= self.horizon
+        self.finished_returns.append(t.where(dones, self.ep_ret, t.full_like(self.ep_ret, float("nan"))))
+        fresh = t.randn((self.num_envs, self.dim), device="cuda", generator=self.gen)
+        self.x = t.where(dones[:, None], fresh, self.x)
+        self.age = t.where(dones, t.zeros_like(self.age), self.age)
+        self.ep_ret = t.where(dones, t.zeros_like(self.ep_ret), self.ep_ret)
+        rews = rew if not self.reward_columns else rew[:, None].repeat(1, self.reward_columns).contiguous()
+        return self.x.clone(), rews, dones, []
+
+    def mean_finished_return(self, last=None):
+        """Mean return of the episodes that ended in the last ``last`` steps (synchronising)."""
+        t = self.torch
+        rows = self.finished_returns[-last:] if last else self.finished_returns
+        return float(t.nanmean(t.stack(rows)).item())
+
+    def close(self):
+        pass

@@ -419,8 +419,9 @@ class PolicySpec:
         return int(lib.ppo2hip_grad_workspace_bytes(ctypes.byref(self.desc), B))
 
 
-def policy_forward(spec, params, obs, workspace, masks=None, states=None):
-    """obs [B, ...] -> (pi [B, ac_dim], vf [B, nvalue], new_states or None)."""
+def policy_forward(spec, params, obs, workspace, masks=None, states=None, vf_out=None):
+    """obs [B, ...] -> (pi [B, ac_dim], vf [B, nvalue], new_states or None); ``vf_out`` may be a
+    preallocated [B, nvalue] row of a rollout arena."""
     params = _dev(params, torch.float32, "params")
     if params.numel() != spec.nparams:
         raise ValueError("params has %d entries, policy needs %d" % (params.numel(), spec.nparams))
@@ -432,7 +433,12 @@ def policy_forward(spec, params, obs, workspace, masks=None, states=None):
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         raise ValueError("forward workspace too small: need %d bytes" % need)
     pi = torch.empty((B, spec.ac_dim), dtype=torch.float32, device=obs.device)
-    vf = torch.empty((B, spec.nvalue), dtype=torch.float32, device=obs.device)
+    if vf_out is None:
+        vf = torch.empty((B, spec.nvalue), dtype=torch.float32, device=obs.device)
+    else:
+        vf = _dev(vf_out, torch.float32, "vf_out")
+        if vf.numel() != B * spec.nvalue:
+            raise ValueError("vf_out must hold [B, %d]" % spec.nvalue)
     snew = None
     if spec.recurrent:
         masks = _dev(_as_u8(masks), torch.uint8, "masks")
@@ -456,6 +462,47 @@ def neglogp(spec, params, pi, actions):
     check(lib.ppo2hip_neglogp(ctypes.byref(spec.desc), _ptr(params), _ptr(pi), _ptr(actions), B, _ptr(out), _stream()),
           "neglogp")
     return out
+
+
+def sample_actions(spec, params, pi, seed, step, deterministic=False, want_noise=False, actions=None, neglogp=None):
+    """Draw actions from ``pi`` [B, ac_dim] and evaluate their neglogp; the noise is a pure function of
+    (seed, step, row, element).  ``actions`` / ``neglogp`` may be preallocated rows of a rollout arena."""
+    pi = _dev(pi, torch.float32, "pi")
+    B = pi.shape[0]
+    if pi.dim() != 2 or pi.shape[1] != spec.ac_dim:
+        raise ValueError("pi must be [B, %d]" % spec.ac_dim)
+    if actions is None:
+        actions = (torch.empty((B, spec.ac_dim), dtype=torch.float32, device=pi.device) if spec.gaussian
+                   else torch.empty(B, dtype=torch.int32, device=pi.device))
+    else:
+        _dev(actions, torch.float32 if spec.gaussian else torch.int32, "actions")
+        if actions.numel() != (B * spec.ac_dim if spec.gaussian else B):
+            raise ValueError("actions has the wrong size")
+    if neglogp is None:
+        neglogp = torch.empty(B, dtype=torch.float32, device=pi.device)
+    elif _dev(neglogp, torch.float32, "neglogp").numel() != B:
+        raise ValueError("neglogp has the wrong size")
+    noise = torch.empty((B, spec.ac_dim), dtype=torch.float32, device=pi.device) if want_noise else None
+    check(lib.ppo2hip_sample_actions(ctypes.byref(spec.desc), _ptr(params), _ptr(pi), B, int(seed) & (2 ** 64 - 1),
+                                     int(step) & (2 ** 64 - 1), int(bool(deterministic)), _ptr(actions), _ptr(neglogp),
+                                     _ptr(noise), _stream()), "sample_actions")
+    return (actions, neglogp, noise) if want_noise else (actions, neglogp)
+
+
+def done_bootstrap(rewards, dones, v_reset, gamma):
+    """In place: rewards[e] += gamma * v_reset[e] for finished envs, by the fork's channel rule."""
+    rewards = _dev(rewards, torch.float32, "rewards")
+    v_reset = _dev(v_reset, torch.float32, "v_reset")
+    if rewards.dim() != 2 or v_reset.shape != rewards.shape:
+        raise ValueError("rewards and v_reset must both be [E, R]")
+    E, R = rewards.shape
+    dones = _dev(_as_u8(dones), torch.uint8, "dones")
+    if dones.numel() != E:
+        raise ValueError("dones must be [E]")
+    g = np.ascontiguousarray(np.broadcast_to(np.asarray(gamma, np.float64), (R,)))
+    check(lib.ppo2hip_done_bootstrap(_ptr(rewards), _ptr(dones), _ptr(v_reset), g.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                     E, R, _stream()), "done_bootstrap")
+    return rewards
 
 
 class RolloutRef:

@@ -412,8 +412,12 @@ class Runner(object):
         self.model = model
         nenv = env.num_envs
         self.nenv = nenv
-        self.obs = np.zeros((nenv,) + env.observation_space.shape, dtype=model.train_model.X.dtype.name)
-        self.obs[:] = env.reset()
+        self.device_env = bool(getattr(env, "device_resident", False))
+        if self.device_env:
+            self._init_device_env(env, model)
+        else:
+            self.obs = np.zeros((nenv,) + env.observation_space.shape, dtype=model.train_model.X.dtype.name)
+            self.obs[:] = env.reset()
         self.gamma = np.array(gamma)
         self.lam = lam
         self.nsteps = nsteps
@@ -422,8 +426,68 @@ class Runner(object):
         self.fork = getattr(model, "signature", "fork") == "fork"
         self.rollout = None
         self.verbose = False
+        self._arena = None
+
+    def _init_device_env(self, env, model):
+        """Envs that simulate in HBM (``env.device_resident``) keep observations, done flags and recurrent
+        states as device tensors between steps."""
+        self.obs_dev = env.reset().contiguous()
+        self.dones_dev = torch.zeros(self.nenv, dtype=torch.uint8, device=model.device)
+        self.states_dev = (torch.from_numpy(np.ascontiguousarray(model.initial_state, np.float32)).to(model.device)
+                           if model.initial_state is not None else None)
+
+    def run_dev(self, use_deterministic=False):
+        """The rollout loop of ``run`` (baselines/ppo2/common_functions.py:247-304) with nothing leaving
+        the device: each step's forward, sampling and neglogp write into row t of the time-major arena,
+        the env steps on device tensors, the fork's done-bootstrap (:265-276) and GAE (:308-328) run in
+        their kernels.  Returns ``run``'s 10-tuple with None in place of the seven flattened host arrays;
+        the collected rollout is ``self.rollout``."""
+        model, spec, T, E = self.model, self.model.spec, self.nsteps, self.nenv
+        pol = model.act_model
+        dev, R = model.device, spec.nvalue
+        if self._arena is None:
+            f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            self._arena = dict(
+                obs=torch.empty((T, E) + tuple(spec.ob_shape()), dtype=spec.ob_dtype(), device=dev),
+                actions=f32(T, E, spec.ac_dim) if spec.gaussian else torch.empty((T, E), dtype=torch.int32, device=dev),
+                rewards=f32(T, E, R), values=f32(T, E, R), nlp=f32(T, E),
+                dones=torch.empty((T, E), dtype=torch.uint8, device=dev))
+        a = self._arena
+        mb_states = self.states_dev.clone() if self.states_dev is not None else None
+        epinfos = []
+        for t in range(T):
+            a["obs"][t].copy_(self.obs_dev)
+            a["dones"][t].copy_(self.dones_dev)
+            actions, _, snew, _ = pol.step_dev(self.obs_dev, self.states_dev, self.dones_dev, use_deterministic,
+                                               actions=a["actions"][t], neglogp=a["nlp"][t], values=a["values"][t])
+            if snew is not None:
+                self.states_dev = snew
+            obs, rewards, dones, infos = self.env.step(actions)
+            self.obs_dev = obs.contiguous()
+            self.dones_dev = dones.view(torch.uint8) if dones.dtype == torch.bool else dones
+            rewards = rewards.to(torch.float32)
+            if self.fork:
+                rewards = rewards[:, :-1].contiguous()                                  # :262
+                # V(reset observation) for every env; the kernel applies it where dones is set (:265-276)
+                hip.done_bootstrap(rewards, self.dones_dev, pol.value_dev(self.obs_dev), self.gamma)
+            a["rewards"][t].copy_(rewards.reshape(E, R))
+            for info in infos:
+                maybeepinfo = info.get('episode')
+                if maybeepinfo:
+                    epinfos.append(maybeepinfo)
+        last_values = pol.value_dev(self.obs_dev, self.states_dev, self.dones_dev).reshape(E, R)   # :304
+        gamma = np.broadcast_to(self.gamma.astype(np.float64), (R,)) if self.gamma.ndim else float(self.gamma)
+        advs, returns, advs_ori = hip.gae(a["rewards"], a["values"], a["dones"], last_values, self.dones_dev, gamma, self.lam)
+        ro = DeviceRollout(T, E, a["obs"], a["actions"], a["rewards"], a["values"], a["nlp"], a["dones"], last_values,
+                           self.dones_dev, states=mb_states)
+        ro.advs_gae, ro.returns, ro.advs_ori = advs, returns, advs_ori
+        self.rollout = ro
+        states_host = mb_states.cpu().numpy() if mb_states is not None else None
+        return (None, None, None, None, None, None, None, states_host, epinfos, False)
 
     def run(self, is_test=False, use_deterministic=False):
+        if self.device_env:
+            return self.run_dev(use_deterministic)
         mb_obs, mb_rewards, mb_actions, mb_values, mb_dones, mb_neglogpacs = [], [], [], [], [], []
         mb_states = self.states
         epinfos = []

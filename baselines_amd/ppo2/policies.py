@@ -17,14 +17,19 @@ from ..a2c.utils import ortho_init
 from ..common.distributions import make_pdtype
 
 _SCOPES = {}
-_sample_rng = np.random.RandomState(0)
+_sample = {"seed": 0, "step": 0}
 
 
 def set_sample_seed(seed):
     """Seed of the action-sampling noise (the reference samples with TensorFlow's own RNG,
-    baselines/common/distributions.py:164-166,211-212, which no other RNG reproduces)."""
-    global _sample_rng
-    _sample_rng = np.random.RandomState(seed)
+    baselines/common/distributions.py:164-166,211-212, which no other RNG reproduces).  The noise of
+    a step is a function of (seed, number of sampling calls since the seed was set, env row)."""
+    _sample["seed"], _sample["step"] = int(seed), 0
+
+
+def _next_sample_step():
+    _sample["step"] += 1
+    return _sample["step"] - 1
 
 
 def reset_scopes():
@@ -104,7 +109,7 @@ def _get_arena(scope, reuse, spec, device):
 
 
 class _HipPolicy:
-    """Shared behaviour: forward in HIP, host-side sampling, neglogp in HIP."""
+    """Shared behaviour: forward, action sampling and neglogp in HIP; the host methods only move arrays."""
 
     recurrent = False
 
@@ -131,20 +136,10 @@ class _HipPolicy:
         ob = np.ascontiguousarray(ob, dtype=np.float32 if self.spec.kind == _lib.POLICY_MLP else np.uint8)
         return torch.from_numpy(ob).to(self.device)
 
-    def forward_dev(self, ob_dev, masks=None, states=None):
+    def forward_dev(self, ob_dev, masks=None, states=None, vf_out=None):
         """Device obs [B, ...] -> (pi, vf, new_states) device tensors."""
-        return hip.policy_forward(self.spec, self.arena.theta, ob_dev, self._workspace(ob_dev.shape[0]), masks, states)
-
-    def _sample(self, pi_host, deterministic=False):
-        if self.spec.gaussian:
-            if deterministic:
-                return pi_host.astype(np.float32)
-            logstd = self.logstd_host()
-            return (pi_host + np.exp(logstd) * _sample_rng.standard_normal(pi_host.shape)).astype(np.float32)
-        if deterministic:
-            return np.argmax(pi_host, axis=-1).astype(np.int32)
-        u = _sample_rng.uniform(size=pi_host.shape)
-        return np.argmax(pi_host - np.log(-np.log(u)), axis=-1).astype(np.int32)   # Gumbel-max
+        return hip.policy_forward(self.spec, self.arena.theta, ob_dev, self._workspace(ob_dev.shape[0]), masks, states,
+                                  vf_out=vf_out)
 
     def logstd_host(self):
         for name, off, shp in self.spec.vars:
@@ -152,18 +147,28 @@ class _HipPolicy:
                 return self.arena.theta[off:off + shp[-1]].cpu().numpy().reshape(1, -1)
         raise AttributeError("policy has no logstd")
 
+    def step_dev(self, ob_dev, state_dev=None, mask_dev=None, deterministic=False, actions=None, neglogp=None,
+                 values=None):
+        """One act step entirely in HBM: forward, sampling and neglogp.  ``actions`` / ``neglogp`` /
+        ``values`` may be rows of a rollout arena to write into.  Returns device (actions, values,
+        new_states, neglogp)."""
+        pi, vf, snew = self.forward_dev(ob_dev, mask_dev, state_dev, vf_out=values)
+        a, nlp = hip.sample_actions(self.spec, self.arena.theta, pi, _sample["seed"], _next_sample_step(), deterministic,
+                                    actions=actions, neglogp=neglogp)
+        return a, vf, snew, nlp
+
+    def value_dev(self, ob_dev, state_dev=None, mask_dev=None):
+        return self.forward_dev(ob_dev, mask_dev, state_dev)[1]
+
     def _act(self, ob, state, mask, deterministic):
         ob_dev = self._to_dev_obs(ob)
         m_dev = s_dev = None
         if self.recurrent:
             m_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(mask).astype(np.uint8))).to(self.device)
             s_dev = torch.from_numpy(np.ascontiguousarray(state, np.float32)).to(self.device)
-        pi, vf, snew = self.forward_dev(ob_dev, m_dev, s_dev)
-        a = self._sample(pi.cpu().numpy(), deterministic)
-        a_dev = torch.from_numpy(a).to(self.device)
-        nlp = hip.neglogp(self.spec, self.arena.theta, pi, a_dev).cpu().numpy()
-        v = vf.cpu().numpy()
-        return a, self._squeeze_v(v), (snew.cpu().numpy() if snew is not None else self.initial_state), nlp
+        a, vf, snew, nlp = self.step_dev(ob_dev, s_dev, m_dev, deterministic)
+        return (a.cpu().numpy(), self._squeeze_v(vf.cpu().numpy()),
+                (snew.cpu().numpy() if snew is not None else self.initial_state), nlp.cpu().numpy())
 
     def _squeeze_v(self, v):
         return v

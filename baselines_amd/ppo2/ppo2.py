@@ -73,6 +73,9 @@ def learn(*, policy, env, nsteps, total_timesteps, ent_coef, lr,
             N, R = ro.T * ro.E, ro.values.shape[2]
             ro.advs = compute_advs(max_return[:R], ro.values.reshape(N, R), ro.advs_ori.reshape(N, R), [], []) \
                 .reshape(ro.T, ro.E)
+        if rewards is None:                       # device-resident env: the rollout never left HBM
+            assert device_path, "an env that lives on the device needs device_path=True"
+            rewards = ro.rewards.mean().item() if (update % log_interval == 0 or update == 1) else 0.0
         if device_path:
             lossvals = model.train_on_rollout(float(lrnow), float(cliprangenow), ro, noptepochs, nbatch_train,
                                                more_updates=update < nupdates).cpu().numpy()

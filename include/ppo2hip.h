@@ -261,6 +261,28 @@ int ppo2hip_neglogp(const ppo2hip_policy_desc *desc, const float *params, const 
                     const void *actions, int64_t B, float *neglogp, void *stream);
 
 size_t ppo2hip_grad_workspace_bytes(const ppo2hip_policy_desc *desc, int64_t B);
+/* Action sampling with its neglogp: `a0 = pd.sample(); neglogp0 = pd.neglogp(a0)` of the act graph,
+ * baselines/ppo2/policies.py:168-170 (fork) and baselines/a2c/policies.py:137-139; Gaussian
+ * `mean + std * N(0,1)` (baselines/common/distributions.py:211-212), Categorical Gumbel-max
+ * `argmax(logits - log(-log(U)))` (:164-166).  The reference draws the noise inside TensorFlow;
+ * here it is Philox4x32-10 keyed by `seed`, counter (row, element group, step), so a (seed, step)
+ * pair reproduces a rollout step's noise on any launch geometry and no generator state is kept.
+ *   pi : float32 [B, ac_dim] mean or logits (ppo2hip_policy_forward's output)
+ *   deterministic != 0 : the mode (`step_max`, baselines/ppo2/policies.py:172-174)
+ *   actions : float32 [B, ac_dim] (Gaussian) or int32 [B] out      neglogp : float32 [B] out
+ *   noise_out : float32 [B, ac_dim] or NULL — the N(0,1) / U(0,1) draws that were used */
+int ppo2hip_sample_actions(const ppo2hip_policy_desc *desc, const float *params, const float *pi, int64_t B,
+                           uint64_t seed, uint64_t step, int deterministic, void *actions, float *neglogp,
+                           float *noise_out, void *stream);
+
+/* The fork's bootstrap of finished envs off the value of the reset observation,
+ * baselines/ppo2/common_functions.py:265-276: where dones[e], rewards[e] += gamma * v_reset[e] on
+ * every channel if rewards[e][0] > 0, else on channels 2.. only.
+ *   rewards : float32 [E, R] in/out    dones : uint8 [E]    v_reset : float32 [E, R]
+ *   gamma : HOST double[R], R <= 8 */
+int ppo2hip_done_bootstrap(float *rewards, const uint8_t *dones, const float *v_reset, const double *gamma,
+                           int64_t E, int R, void *stream);
+
 /* One Model.train graph evaluation up to (not including) the optimiser,
  * baselines/ppo2/common_functions.py:26-44 + the tf.gradients of :53-54/:57:
  * gathers the minibatch, normalises advantages with `stats` (from ppo2hip_adv_stats,
