@@ -58,7 +58,7 @@ def dense_flops_per_sample(D, hidden, A, R):
 def measured_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate
     rocprofv3 runs of this script), or None when no profile of this workload is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_d_hbm_traffic.json")
     try:
         with open(path) as fh:
             prof = json.load(fh)
