@@ -46,8 +46,29 @@ struct Im2col {   // A(m, k)
     __device__ Row row(int64_t m) const { return patch_row(g, m).base; }
     __device__ Col col(int64_t k) const { return tap_offset(g, k); }
     __device__ float at(const Row &r, const Col &c) const {
-        if (U8) return (float)((const uint8_t *)x)[r + c] / 255.0f;
+        if (U8) return (float)((const uint8_t *)x)[r + c] * (1.0f / 255.0f);
         return ((const float *)x)[r + c];
+    }
+    // 16 bytes per load: sixteen uint8 taps, or four float taps, of one kernel row (kw, ci run contiguously)
+    static constexpr int kVec = U8 ? 16 : 4;
+    int vec_width() const {
+        const int esz = U8 ? 1 : 4;
+        const bool ok = aligned16(x) && (g.KW * g.Cin) % kVec == 0 && (g.Cin * esz) % 4 == 0 &&
+                        (g.IW * g.Cin * esz) % 16 == 0 && (g.S * g.Cin * esz) % 16 == 0;
+        return ok ? kVec : 1;
+    }
+    __device__ void at_vec(const Row &r, const Col &c, float (&o)[kVec]) const {
+        if constexpr (U8) {
+            const uint4 v = *(const uint4 *)((const uint8_t *)x + r + c);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[4 * q + j] = (float)((w[q] >> (8 * j)) & 0xffu) * (1.0f / 255.0f);
+        } else {
+            const float4 v = *(const float4 *)((const float *)x + r + c);
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        }
     }
 };
 
@@ -68,6 +89,9 @@ struct Im2colT {   // A(i = k, kk = m), row `ones_row` = 1
         p.base = (((int64_t)p.b * g.IH + p.oh * g.S) * g.IW + p.ow * g.S) * g.Cin;
     }
     __device__ float at(const Row &r, const Col &p) const { return r < 0 ? 1.f : c.at(p.base, r); }
+    static constexpr int kVec = Im2col<U8>::kVec;
+    int vec_width() const { return ones_row < 0 ? c.vec_width() : 1; }     // no row of ones among wide loads
+    __device__ void at_vec(const Row &r, const Col &p, float (&o)[kVec]) const { c.at_vec(p.base, r, o); }
 };
 
 struct PixelRow {   // pixel (ih, iw) of image b in the dgrad row space; bbase = offset of dY[b, 0, 0, 0]
@@ -111,10 +135,23 @@ struct DgradCol {   // A(m = (b,ih,iw), k = (kh,kw,co)) = dY[b, (ih-kh)/s, (iw-k
         if (oh * g.S != th || ow * g.S != tw || oh >= g.OH || ow >= g.OW) return 0.f;
         return dy[p.bbase + (int64_t)(oh * g.OW + ow) * g.Cout + t.co];
     }
+    static constexpr int kVec = 4;      // four output channels of one tap
+    int vec_width() const { return aligned16(dy) && g.Cout % 4 == 0 ? 4 : 1; }
+    __device__ void at_vec(const Row &p, const Col &t, float (&o)[4]) const {
+        const int th = p.ih - t.kh, tw = p.iw - t.kw;
+        const int oh = th / g.S, ow = tw / g.S;
+        if (th < 0 || tw < 0 || oh * g.S != th || ow * g.S != tw || oh >= g.OH || ow >= g.OW) {
+            o[0] = o[1] = o[2] = o[3] = 0.f;
+            return;
+        }
+        const float4 v = *(const float4 *)(dy + p.bbase + (int64_t)(oh * g.OW + ow) * g.Cout + t.co);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
 };
 
 struct DgradW {   // B(k = (kh,kw,co), n = ci) = W[kh, kw, ci, co]
     static constexpr bool kInnerFast = false;
+    static constexpr int kVec = 1;
     typedef int Row;
     typedef int Col;
     const float *w;
@@ -155,7 +192,7 @@ int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape 
     *nslabs = n;
     RowMajor Bm{dY, c.Cout};
     EpiSlab ep{slabs, c.Cout, (int64_t)(K + 1) * c.Cout};
-    const bool sep = wgrad_bias_separately(K);         // ones-row only where it does not cost an extra row tile
+    const bool sep = wgrad_bias_separately(K);         // ones-row only where it does not stand in the way of wide loads
     const int64_t ones = sep ? -1 : K, rows = sep ? K : K + 1;
     int rc;
     if (x_u8) rc = launch_gemm(Im2colT<true>{Im2col<true>{X, geom(c)}, ones}, Bm, ep, rows, c.Cout, M, n, s, "conv_wgrad");
@@ -190,9 +227,21 @@ struct DgradColP {   // A(m' = (b, ih', iw'), k' = (kh', kw', co)),  ih = S ih' 
         if (oh < 0 || ow < 0 || oh >= g.OH || ow >= g.OW) return 0.f;
         return dy[p.bbase + (int64_t)(oh * g.OW + ow) * g.Cout + t.co];
     }
+    static constexpr int kVec = 4;
+    int vec_width() const { return aligned16(dy) && g.Cout % 4 == 0 ? 4 : 1; }
+    __device__ void at_vec(const Row &p, const Col &t, float (&o)[4]) const {
+        const int oh = p.ih - t.kh, ow = p.iw - t.kw;
+        if (oh < 0 || ow < 0 || oh >= g.OH || ow >= g.OW) {
+            o[0] = o[1] = o[2] = o[3] = 0.f;
+            return;
+        }
+        const float4 v = *(const float4 *)(dy + p.bbase + (int64_t)(oh * g.OW + ow) * g.Cout + t.co);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
 };
 struct DgradWP {   // B(k' = (kh', kw', co), n = ci) = W[ph + S kh', pw + S kw', ci, co]
     static constexpr bool kInnerFast = false;
+    static constexpr int kVec = 1;
     typedef int Row;
     typedef int Col;
     const float *w;

@@ -38,12 +38,12 @@ static int pick_slabs(int64_t S, int64_t tiles) {
 
 int wgrad_max_slabs(int64_t S, int Kin, int N) {
     const int rows = wgrad_bias_separately(Kin) ? Kin : Kin + 1;
-    const int64_t tiles = ceil_div(rows, (Kin + 1) <= 64 ? 64 : 128) * ceil_div(N, N <= 32 ? 32 : GEMM_BN);
+    const int64_t tiles = ceil_div(rows, rows <= 64 ? 64 : 128) * ceil_div(N, (rows > 64 && N <= 32) ? 32 : GEMM_BN);
     return pick_slabs(S, tiles);
 }
 
-// Column sums of dY over each slab's rows, written to row Kin of that slab: the bias gradient where the
-// ones-row would cost the product a whole extra row tile (Kin a multiple of the tile height).
+// Column sums of dY over each slab's rows, written to row Kin of that slab: the bias gradient where a row of
+// ones inside the product would stand in the way of the operand's 16-byte loads (Kin a multiple of 16).
 __global__ __launch_bounds__(256) void slab_colsum_kernel(const float *__restrict__ dY, int64_t lddy, int64_t S, int N,
                                                           int64_t klen, float *__restrict__ slabs, int64_t zstride,
                                                           int64_t row_off) {
@@ -68,10 +68,7 @@ __global__ __launch_bounds__(256) void slab_colsum_kernel(const float *__restric
     if (grp == 0 && n < N) slabs[z * zstride + row_off + n] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
-bool wgrad_bias_separately(int Kin) {
-    const int tile = (Kin + 1) <= 64 ? 64 : 128;
-    return Kin % tile == 0;
-}
+bool wgrad_bias_separately(int Kin) { return Kin % 16 == 0; }
 
 int slab_bias_rows(const float *dY, int lddy, int64_t S, int Kin, int N, float *slabs, int nslabs, hipStream_t s) {
     int64_t klen = ceil_div(S > 0 ? S : 1, nslabs);

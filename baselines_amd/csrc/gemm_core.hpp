@@ -3,7 +3,7 @@
 // products (split over the sample axis into slabs) all share one LDS-tiled main loop.
 //
 // Tile: BM x BN x 16 (128 x 64, 64 x 64 or, for outputs of at most 32 columns, 128 x 32), 256 threads =
-// 4 wave64.  v_mfma_f32_32x32x2_f32 is an exact fp32
+// 4 wave64; operands reach LDS element by element or, where pointers and strides allow, by 16-byte loads.  v_mfma_f32_32x32x2_f32 is an exact fp32
 // fma chain, so results are reproducible and within fp32 rounding of a float64 reference.
 //   operand lanes : A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31]
 //   result lanes  : C[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
@@ -11,6 +11,8 @@
 // consecutive floats (conflict-free).  The next k-slab is prefetched into registers while
 // the current one feeds the matrix cores.
 #pragma once
+#include <cstdint>
+
 #include "common.hpp"
 
 namespace ppo2hip {
@@ -27,24 +29,38 @@ constexpr int GEMM_THREADS = 256;
 //     float at(const Row &, const Col &) const;
 //     static constexpr bool kInnerFast — true when the SECOND coordinate is the contiguous one in memory
 //                                        (drives the thread->element mapping for coalescing).
+//     static constexpr int kVec;  int vec_width() const (host);  void at_vec(const Row &, const Col &, float (&)[kVec]) const
+//         — kVec > 1: one wide load returns kVec consecutive elements along the contiguous coordinate, starting at
+//           a multiple of kVec; vec_width() says on the host whether this operand's pointers and strides allow it
+//           (kVec) or not (1).
 //   A thread's elements share one coordinate and differ in the other, and only the k coordinate moves from
 //   slab to slab, so the index arithmetic of an implicit-GEMM loader (divisions that split a row number into
-//   image / pixel, a column into tap / channel) runs once per tile or once per slab instead of once per element.
+//   image / pixel, a column into tap / channel) runs once per tile or once per slab instead of once per element;
+//   on the vector path it also runs once per kVec elements, which is what keeps the main loop's VALU work below
+//   its MFMA work for the narrow (few output columns) and byte-input products.
 // Epilogue concept: void operator()(int64_t m, int64_t n, float acc, int z) const
+
+// LDS row pitch: rows lh = 0 / 1 of an operand read must land on different bank halves (pitch = 32 mod 64)
+// when rows are written as vectors; the scalar path keeps the odd pitch that spreads its k-fast writes.
+__host__ __device__ constexpr int lds_pitch(int width, bool vec) { return vec ? (width % 64 == 0 ? width + 32 : width) : width + 1; }
 
 // WM = number of wave rows, NB = 32-column blocks per wave:
 //   <4, 2>: 128 x 64, each wave 32 x 64;  <2, 1>: 64 x 64, each wave 32 x 32;  <4, 1>: 128 x 32, each wave 32 x 32
-template <class AL, class BL, class EP, int WM, int NB>
+// AV / BV = vector width of the A / B loads (1 = element-wise)
+template <class AL, class BL, class EP, int WM, int NB, int AV, int BV>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, int64_t M, int N, int64_t K,
                                                             int64_t klen) {
     constexpr int BM = 32 * WM;
     constexpr int WN = 4 / WM;              // wave columns
     constexpr int BN = 32 * WN * NB;
-    constexpr int LDA = BM + 1, LDB = BN + 1;
-    constexpr int A_PER = BM * GEMM_BK / GEMM_THREADS;
-    constexpr int B_PER = BN * GEMM_BK / GEMM_THREADS;
-    __shared__ float As[GEMM_BK * LDA];
-    __shared__ float Bs[GEMM_BK * LDB];
+    constexpr int LDA = lds_pitch(BM, AV > 1), LDB = lds_pitch(BN, BV > 1);
+    // element-wise: elements per thread; vector: tasks (one wide load each) per thread
+    constexpr int A_TASKS_ALL = BM * GEMM_BK / AV, B_TASKS_ALL = BN * GEMM_BK / BV;
+    constexpr int A_PER = (A_TASKS_ALL + GEMM_THREADS - 1) / GEMM_THREADS;
+    constexpr int B_PER = (B_TASKS_ALL + GEMM_THREADS - 1) / GEMM_THREADS;
+    static_assert(BV == 1 || BL::kInnerFast, "vector loads of B run along n");
+    __shared__ __attribute__((aligned(16))) float As[GEMM_BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[GEMM_BK * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -61,21 +77,40 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[nb][r] = 0.f;
 
-    float areg[A_PER], breg[B_PER];
+    float areg[A_PER][AV], breg[B_PER][BV];
 
-    // thread -> element mapping (element e of the thread is tile entry lin = tid + e * 256)
+    // thread -> element mapping, element-wise path (element e of the thread is tile entry lin = tid + e * 256)
     //   A, kInnerFast : k = lin % 16 is the thread's own, rows differ with e          (row contexts: once)
     //   A, otherwise  : m = lin % BM is the thread's own, k differs with e and slab    (col contexts: advanced)
     //   B, kInnerFast : n = lin % BN is the thread's own, k differs with e and slab    (row contexts: advanced)
     //   B, otherwise  : k = lin % 16 is the thread's own, n differs with e             (col contexts: once)
+    // vector path (task t = tid + e * 256 is one wide load)
+    //   A, kInnerFast : row m = t % BM is the thread's own (lanes along m: conflict-free LDS writes), the task's
+    //                   k group is t / BM                                               (row context: once)
+    //   A, otherwise  : m group t % (BM/AV), k = t / (BM/AV), advanced from slab to slab (LDS rows written as float4)
+    //   B (n-fast)    : n group t % (BN/BV), k = t / (BN/BV), advanced from slab to slab
     constexpr int A_KSTEP = GEMM_THREADS / BM;          // k distance between a thread's elements (A, m-fast mapping)
     constexpr int B_KSTEP = GEMM_THREADS / BN;
-    typename AL::Row arow[AL::kInnerFast ? A_PER : 1];
-    typename AL::Col acol[AL::kInnerFast ? 1 : A_PER];
+    constexpr int A_MG = BM / AV, B_NG = BN / BV;       // groups along the contiguous coordinate (vector path)
+    constexpr bool A_ROWS_ONCE = AL::kInnerFast;        // which context array is per-element
+    typename AL::Row arow[(AV == 1 && A_ROWS_ONCE) ? A_PER : 1];
+    typename AL::Col acol[A_ROWS_ONCE ? 1 : A_PER];
     typename BL::Row brow[BL::kInnerFast ? B_PER : 1];
     typename BL::Col bcol[BL::kInnerFast ? 1 : B_PER];
-    bool a_ok[AL::kInnerFast ? A_PER : 1], b_ok[BL::kInnerFast ? 1 : B_PER];
-    if constexpr (AL::kInnerFast) {
+    bool a_ok[(AV == 1 && A_ROWS_ONCE) ? A_PER : 1], b_ok[BL::kInnerFast ? 1 : B_PER];
+    if constexpr (AV > 1) {
+        if constexpr (AL::kInnerFast) {
+            const int64_t m = m0 + tid % BM;
+            a_ok[0] = m < M;
+            arow[0] = a.row(a_ok[0] ? m : 0);
+        } else {
+            const int64_t m = m0 + (tid % A_MG) * AV;
+            a_ok[0] = m < M;                             // M is a multiple of AV: a group is all in or all out
+            arow[0] = a.row(a_ok[0] ? m : 0);
+#pragma unroll
+            for (int e = 0; e < A_PER; e++) acol[e] = a.col(kbeg + (tid + e * GEMM_THREADS) / A_MG);
+        }
+    } else if constexpr (AL::kInnerFast) {
 #pragma unroll
         for (int e = 0; e < A_PER; e++) {
             const int64_t m = m0 + (tid + e * GEMM_THREADS) / GEMM_BK;
@@ -89,7 +124,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
 #pragma unroll
         for (int e = 0; e < A_PER; e++) acol[e] = a.col(kbeg + tid / BM + e * A_KSTEP);
     }
-    if constexpr (BL::kInnerFast) {
+    if constexpr (BV > 1) {
+        const int n = n0 + (tid % B_NG) * BV;
+        b_ok[0] = n < N;                                 // N is a multiple of BV
+        bcol[0] = b.col(b_ok[0] ? n : 0);
+#pragma unroll
+        for (int e = 0; e < B_PER; e++) brow[e] = b.row(kbeg + (tid + e * GEMM_THREADS) / B_NG);
+    } else if constexpr (BL::kInnerFast) {
         const int n = n0 + tid % BN;
         b_ok[0] = n < N;
         bcol[0] = b.col(b_ok[0] ? n : 0);
@@ -106,25 +147,63 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
 
     // loads slab [k0, k0 + 16); the advancing contexts stand at k0 on entry and at k0 + 16 on exit
     auto fetch = [&](int64_t k0) {
-        if constexpr (AL::kInnerFast) {
+        if constexpr (AV > 1 && AL::kInnerFast) {
+#pragma unroll
+            for (int e = 0; e < A_PER; e++) {
+                const int t = tid + e * GEMM_THREADS;
+                const int64_t k = k0 + (t / BM) * AV;                       // K is a multiple of AV
+                if (t < A_TASKS_ALL && a_ok[0] && k < kend) {
+                    a.at_vec(arow[0], a.col(k), areg[e]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < AV; j++) areg[e][j] = 0.f;
+                }
+            }
+        } else if constexpr (AV > 1) {
+#pragma unroll
+            for (int e = 0; e < A_PER; e++) {
+                const int t = tid + e * GEMM_THREADS;
+                const int64_t k = k0 + t / A_MG;
+                if (t < A_TASKS_ALL && a_ok[0] && k < kend) {
+                    a.at_vec(arow[0], acol[e], areg[e]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < AV; j++) areg[e][j] = 0.f;
+                }
+                a.advance_col(acol[e], GEMM_BK);
+            }
+        } else if constexpr (AL::kInnerFast) {
             const int64_t k = k0 + tid % GEMM_BK;
             const bool kok = k < kend;
             acol[0] = a.col(kok ? k : kbeg);
 #pragma unroll
-            for (int e = 0; e < A_PER; e++) areg[e] = (kok && a_ok[e]) ? a.at(arow[e], acol[0]) : 0.f;
+            for (int e = 0; e < A_PER; e++) areg[e][0] = (kok && a_ok[e]) ? a.at(arow[e], acol[0]) : 0.f;
         } else {
 #pragma unroll
             for (int e = 0; e < A_PER; e++) {
                 const int64_t k = k0 + tid / BM + e * A_KSTEP;
-                areg[e] = (a_ok[0] && k < kend) ? a.at(arow[0], acol[e]) : 0.f;
+                areg[e][0] = (a_ok[0] && k < kend) ? a.at(arow[0], acol[e]) : 0.f;
                 a.advance_col(acol[e], GEMM_BK);
             }
         }
-        if constexpr (BL::kInnerFast) {
+        if constexpr (BV > 1) {
+#pragma unroll
+            for (int e = 0; e < B_PER; e++) {
+                const int t = tid + e * GEMM_THREADS;
+                const int64_t k = k0 + t / B_NG;
+                if (t < B_TASKS_ALL && b_ok[0] && k < kend) {
+                    b.at_vec(brow[e], bcol[0], breg[e]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < BV; j++) breg[e][j] = 0.f;
+                }
+                b.advance_row(brow[e], GEMM_BK);
+            }
+        } else if constexpr (BL::kInnerFast) {
 #pragma unroll
             for (int e = 0; e < B_PER; e++) {
                 const int64_t k = k0 + tid / BN + e * B_KSTEP;
-                breg[e] = (b_ok[0] && k < kend) ? b.at(brow[e], bcol[0]) : 0.f;
+                breg[e][0] = (b_ok[0] && k < kend) ? b.at(brow[e], bcol[0]) : 0.f;
                 b.advance_row(brow[e], GEMM_BK);
             }
         } else {
@@ -132,25 +211,45 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
             const bool kok = k < kend;
             brow[0] = b.row(kok ? k : kbeg);
 #pragma unroll
-            for (int e = 0; e < B_PER; e++) breg[e] = (kok && b_ok[e]) ? b.at(brow[0], bcol[e]) : 0.f;
+            for (int e = 0; e < B_PER; e++) breg[e][0] = (kok && b_ok[e]) ? b.at(brow[0], bcol[e]) : 0.f;
         }
     };
     auto stash = [&]() {
 #pragma unroll
         for (int e = 0; e < A_PER; e++) {
             const int lin = tid + e * GEMM_THREADS;
-            int ml, kl;
-            if (AL::kInnerFast) { kl = lin % GEMM_BK; ml = lin / GEMM_BK; }
-            else { ml = lin % BM; kl = lin / BM; }
-            As[kl * LDA + ml] = areg[e];
+            if constexpr (AV > 1 && AL::kInnerFast) {
+                if (lin < A_TASKS_ALL) {
+                    const int ml = lin % BM, kg = lin / BM;
+#pragma unroll
+                    for (int j = 0; j < AV; j++) As[(kg * AV + j) * LDA + ml] = areg[e][j];
+                }
+            } else if constexpr (AV > 1) {
+                if (lin < A_TASKS_ALL) {
+                    float *dst = &As[(lin / A_MG) * LDA + (lin % A_MG) * AV];
+#pragma unroll
+                    for (int q = 0; q < AV / 4; q++)
+                        *(float4 *)(dst + 4 * q) = make_float4(areg[e][4 * q], areg[e][4 * q + 1], areg[e][4 * q + 2], areg[e][4 * q + 3]);
+                }
+            } else {
+                int ml, kl;
+                if (AL::kInnerFast) { kl = lin % GEMM_BK; ml = lin / GEMM_BK; }
+                else { ml = lin % BM; kl = lin / BM; }
+                As[kl * LDA + ml] = areg[e][0];
+            }
         }
 #pragma unroll
         for (int e = 0; e < B_PER; e++) {
             const int lin = tid + e * GEMM_THREADS;
-            int kl, nl;
-            if (BL::kInnerFast) { nl = lin % BN; kl = lin / BN; }
-            else { kl = lin % GEMM_BK; nl = lin / GEMM_BK; }
-            Bs[kl * LDB + nl] = breg[e];
+            if constexpr (BV > 1) {
+                if (lin < B_TASKS_ALL)
+                    *(float4 *)&Bs[(lin / B_NG) * LDB + (lin % B_NG) * BV] = make_float4(breg[e][0], breg[e][1], breg[e][2], breg[e][3]);
+            } else {
+                int kl, nl;
+                if (BL::kInnerFast) { nl = lin % BN; kl = lin / BN; }
+                else { kl = lin % GEMM_BK; nl = lin / GEMM_BK; }
+                Bs[kl * LDB + nl] = breg[e][0];
+            }
         }
     };
 
@@ -183,6 +282,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     }
 }
 
+template <class AL, class BL, class EP, int AV, int BV>
+inline int launch_gemm_v(const AL &a, const BL &b, const EP &ep, int64_t M, int N, int64_t K, int64_t klen, dim3 grid,
+                         bool small_m, bool narrow, hipStream_t s, const char *what) {
+    if (small_m)
+        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 2, 1, AV, BV>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
+    else if (narrow)
+        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 1, AV, BV>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
+    else
+        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 2, AV, BV>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
+    return check_launch(what);
+}
+
 template <class AL, class BL, class EP>
 inline int launch_gemm(const AL &a, const BL &b, const EP &ep, int64_t M, int N, int64_t K, int nsplit,
                        hipStream_t s, const char *what) {
@@ -199,18 +310,34 @@ inline int launch_gemm(const AL &a, const BL &b, const EP &ep, int64_t M, int N,
         return PPO2HIP_EINVAL;
     }
     dim3 grid((unsigned)gx, (unsigned)ceil_div(N, BN), (unsigned)nsplit);
-    if (small_m)
-        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 2, 1>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
-    else if (narrow)
-        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 1>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
-    else
-        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 2>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
-    return check_launch(what);
+    // wide loads where the operand allows them and the coordinate they run along comes in whole groups
+    constexpr int AVmax = AL::kVec, BVmax = BL::kInnerFast ? BL::kVec : 1;
+    const bool av = AVmax > 1 && a.vec_width() == AVmax && (AL::kInnerFast ? K % AVmax == 0 : M % AVmax == 0);
+    bool bv = false;
+    if constexpr (BVmax > 1) bv = b.vec_width() == BVmax && N % BVmax == 0;
+    if constexpr (AVmax > 1 && BVmax > 1) {
+        if (av && bv) return launch_gemm_v<AL, BL, EP, AVmax, BVmax>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
+    }
+    if constexpr (AVmax > 1) {
+        if (av) return launch_gemm_v<AL, BL, EP, AVmax, 1>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
+    }
+    if constexpr (BVmax > 1) {
+        if (bv) return launch_gemm_v<AL, BL, EP, 1, BVmax>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
+    }
+    return launch_gemm_v<AL, BL, EP, 1, 1>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
 }
 
 // ---- loaders ---------------------------------------------------------------------------
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
 struct RowMajor {   // element (r, c) at p[r*ld + c]
     static constexpr bool kInnerFast = true;
+    static constexpr int kVec = 4;
+    int vec_width() const { return aligned16(p) && ld % 4 == 0 ? 4 : 1; }
+    __device__ void at_vec(const int64_t &r, const int64_t &c, float (&o)[4]) const {
+        const float4 v = *(const float4 *)(p + r + c);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
     typedef int64_t Row;
     typedef int64_t Col;
     const float *p;
@@ -223,6 +350,12 @@ struct RowMajor {   // element (r, c) at p[r*ld + c]
 };
 struct Transposed {  // element (r, c) at p[c*ld + r]
     static constexpr bool kInnerFast = false;
+    static constexpr int kVec = 4;
+    int vec_width() const { return aligned16(p) && ld % 4 == 0 ? 4 : 1; }
+    __device__ void at_vec(const int64_t &r, const int64_t &c, float (&o)[4]) const {
+        const float4 v = *(const float4 *)(p + r + c);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
     typedef int64_t Row;
     typedef int64_t Col;
     const float *p;
@@ -235,6 +368,12 @@ struct Transposed {  // element (r, c) at p[c*ld + r]
 };
 struct TransposedOnes {  // as Transposed, plus a row `ones_row` of 1.0 (folds the bias gradient in)
     static constexpr bool kInnerFast = false;
+    static constexpr int kVec = 4;
+    int vec_width() const { return ones_row < 0 && aligned16(p) && ld % 4 == 0 ? 4 : 1; }   // no ones row among wide loads
+    __device__ void at_vec(const int64_t &r, const int64_t &c, float (&o)[4]) const {
+        const float4 v = *(const float4 *)(p + r + c);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
     typedef int64_t Row;     // -1 = the row of ones
     typedef int64_t Col;
     const float *p;
