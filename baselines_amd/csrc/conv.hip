@@ -29,25 +29,41 @@ __device__ inline PatchRow patch_row(const ConvGeom &g, int64_t m) {
     p.base = (((int64_t)p.b * g.IH + p.oh * g.S) * g.IW + p.ow * g.S) * g.Cin;
     return p;
 }
-// offset of tap k = (kh, kw, ci) inside a patch
-__device__ inline int tap_offset(const ConvGeom &g, int64_t k) {
+// tap k = (kh, kw, ci) inside a patch: its offset from the patch's first element, and where it stands in its
+// kernel row (kw, ci run contiguously), so that moving on by d taps needs no division
+struct TapOff {
+    int off, rest;
+};
+__device__ inline TapOff tap_offset(const ConvGeom &g, int64_t k) {
     const int kc = g.KW * g.Cin;
     const int kh = (int)k / kc;
-    return kh * g.IW * g.Cin + ((int)k - kh * kc);
+    const int rest = (int)k - kh * kc;
+    return TapOff{kh * g.IW * g.Cin + rest, rest};
+}
+__device__ inline void tap_advance(const ConvGeom &g, TapOff &t, int d) {
+    const int kc = g.KW * g.Cin;
+    t.rest += d;
+    t.off += d;
+    while (t.rest >= kc) {
+        t.rest -= kc;
+        t.off += g.IW * g.Cin - kc;
+    }
 }
 
 template <bool U8>
 struct Im2col {   // A(m, k)
     static constexpr bool kInnerFast = true;
     typedef int64_t Row;
-    typedef int Col;
+    typedef TapOff Col;
     const void *x;
     ConvGeom g;
     __device__ Row row(int64_t m) const { return patch_row(g, m).base; }
     __device__ Col col(int64_t k) const { return tap_offset(g, k); }
-    __device__ float at(const Row &r, const Col &c) const {
-        if (U8) return (float)((const uint8_t *)x)[r + c] * (1.0f / 255.0f);
-        return ((const float *)x)[r + c];
+    __device__ void advance_col(Col &c, int d) const { tap_advance(g, c, d); }
+    __device__ float at(const Row &r, const Col &c) const { return at_off(r, c.off); }
+    __device__ float at_off(int64_t r, int off) const {
+        if (U8) return (float)((const uint8_t *)x)[r + off] * (1.0f / 255.0f);
+        return ((const float *)x)[r + off];
     }
     // 16 bytes per load: sixteen uint8 taps, or four float taps, of one kernel row (kw, ci run contiguously)
     static constexpr int kVec = U8 ? 16 : 4;
@@ -57,7 +73,8 @@ struct Im2col {   // A(m, k)
                         (g.IW * g.Cin * esz) % 16 == 0 && (g.S * g.Cin * esz) % 16 == 0;
         return ok ? kVec : 1;
     }
-    __device__ void at_vec(const Row &r, const Col &c, float (&o)[kVec]) const {
+    __device__ void at_vec(const Row &r, const Col &c, float (&o)[kVec]) const { at_vec_off(r, c.off, o); }
+    __device__ void at_vec_off(int64_t r, int c, float (&o)[kVec]) const {
         if constexpr (U8) {
             const uint4 v = *(const uint4 *)((const uint8_t *)x + r + c);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -79,7 +96,7 @@ struct Im2colT {   // A(i = k, kk = m), row `ones_row` = 1
     typedef PatchRow Col;
     Im2col<U8> c;
     int64_t ones_row;
-    __device__ Row row(int64_t i) const { return i == ones_row ? -1 : tap_offset(c.g, i); }
+    __device__ Row row(int64_t i) const { return i == ones_row ? -1 : tap_offset(c.g, i).off; }
     __device__ Col col(int64_t m) const { return patch_row(c.g, m); }
     __device__ void advance_col(Col &p, int d) const {      // d output pixels further on
         const ConvGeom &g = c.g;
@@ -88,10 +105,10 @@ struct Im2colT {   // A(i = k, kk = m), row `ones_row` = 1
         while (p.oh >= g.OH) { p.oh -= g.OH; p.b++; }
         p.base = (((int64_t)p.b * g.IH + p.oh * g.S) * g.IW + p.ow * g.S) * g.Cin;
     }
-    __device__ float at(const Row &r, const Col &p) const { return r < 0 ? 1.f : c.at(p.base, r); }
+    __device__ float at(const Row &r, const Col &p) const { return r < 0 ? 1.f : c.at_off(p.base, r); }
     static constexpr int kVec = Im2col<U8>::kVec;
     int vec_width() const { return ones_row < 0 ? c.vec_width() : 1; }     // no row of ones among wide loads
-    __device__ void at_vec(const Row &r, const Col &p, float (&o)[kVec]) const { c.at_vec(p.base, r, o); }
+    __device__ void at_vec(const Row &r, const Col &p, float (&o)[kVec]) const { c.at_vec_off(p.base, r, o); }
 };
 
 struct PixelRow {   // pixel (ih, iw) of image b in the dgrad row space; bbase = offset of dY[b, 0, 0, 0]
@@ -111,6 +128,13 @@ __device__ inline TapCol tap_col(int KW, int Cout, int64_t k) {
     return t;
 }
 
+// d taps further on in (kh, kw, co) order
+__device__ inline void tap_col_advance(int KW, int Cout, TapCol &t, int d) {
+    t.co += d;
+    while (t.co >= Cout) { t.co -= Cout; t.kw++; }
+    while (t.kw >= KW) { t.kw -= KW; t.kh++; }
+}
+
 struct DgradCol {   // A(m = (b,ih,iw), k = (kh,kw,co)) = dY[b, (ih-kh)/s, (iw-kw)/s, co] or 0
     static constexpr bool kInnerFast = true;
     typedef PixelRow Row;
@@ -128,6 +152,7 @@ struct DgradCol {   // A(m = (b,ih,iw), k = (kh,kw,co)) = dY[b, (ih-kh)/s, (iw-k
         return p;
     }
     __device__ Col col(int64_t k) const { return tap_col(g.KW, g.Cout, k); }
+    __device__ void advance_col(Col &t, int d) const { tap_col_advance(g.KW, g.Cout, t, d); }
     __device__ float at(const Row &p, const Col &t) const {
         const int th = p.ih - t.kh, tw = p.iw - t.kw;
         if (th < 0 || tw < 0) return 0.f;
@@ -152,16 +177,14 @@ struct DgradCol {   // A(m = (b,ih,iw), k = (kh,kw,co)) = dY[b, (ih-kh)/s, (iw-k
 struct DgradW {   // B(k = (kh,kw,co), n = ci) = W[kh, kw, ci, co]
     static constexpr bool kInnerFast = false;
     static constexpr int kVec = 1;
-    typedef int Row;
+    typedef TapCol Row;
     typedef int Col;
     const float *w;
     ConvGeom g;
-    __device__ Row row(int64_t k) const {
-        const TapCol t = tap_col(g.KW, g.Cout, k);
-        return (t.kh * g.KW + t.kw) * g.Cin * g.Cout + t.co;
-    }
+    __device__ Row row(int64_t k) const { return tap_col(g.KW, g.Cout, k); }
+    __device__ void advance_row(Row &t, int d) const { tap_col_advance(g.KW, g.Cout, t, d); }
     __device__ Col col(int64_t n) const { return (int)n * g.Cout; }
-    __device__ float at(const Row &r, const Col &c) const { return w[r + c]; }
+    __device__ float at(const Row &t, const Col &c) const { return w[(t.kh * g.KW + t.kw) * g.Cin * g.Cout + t.co + c]; }
 };
 
 static ConvGeom geom(const ConvShape &c) {
@@ -222,6 +245,7 @@ struct DgradColP {   // A(m' = (b, ih', iw'), k' = (kh', kw', co)),  ih = S ih' 
         return p;
     }
     __device__ Col col(int64_t k) const { return tap_col(KWp, g.Cout, k); }
+    __device__ void advance_col(Col &t, int d) const { tap_col_advance(KWp, g.Cout, t, d); }
     __device__ float at(const Row &p, const Col &t) const {
         const int oh = p.ih - t.kh, ow = p.iw - t.kw;
         if (oh < 0 || ow < 0 || oh >= g.OH || ow >= g.OW) return 0.f;
@@ -242,31 +266,32 @@ struct DgradColP {   // A(m' = (b, ih', iw'), k' = (kh', kw', co)),  ih = S ih' 
 struct DgradWP {   // B(k' = (kh', kw', co), n = ci) = W[ph + S kh', pw + S kw', ci, co]
     static constexpr bool kInnerFast = false;
     static constexpr int kVec = 1;
-    typedef int Row;
+    typedef TapCol Row;
     typedef int Col;
     const float *w;
     ConvGeom g;
     int ph, pw, KWp;
-    __device__ Row row(int64_t k) const {
-        const TapCol t = tap_col(KWp, g.Cout, k);
-        return ((ph + g.S * t.kh) * g.KW + pw + g.S * t.kw) * g.Cin * g.Cout + t.co;
-    }
+    __device__ Row row(int64_t k) const { return tap_col(KWp, g.Cout, k); }
+    __device__ void advance_row(Row &t, int d) const { tap_col_advance(KWp, g.Cout, t, d); }
     __device__ Col col(int64_t n) const { return (int)n * g.Cout; }
-    __device__ float at(const Row &r, const Col &c) const { return w[r + c]; }
+    __device__ float at(const Row &t, const Col &c) const {
+        return w[((ph + g.S * t.kh) * g.KW + pw + g.S * t.kw) * g.Cin * g.Cout + t.co + c];
+    }
 };
 struct EpiActGradP {   // row m' of a parity class -> pixel (b, S ih' + ph, S iw' + pw) of dX, times relu'(X)
+    typedef int64_t Row;   // offset of that pixel's first channel
     float *dX;
     const float *Xact;
     ConvGeom g;
     int ph, pw, IHp, IWp;
-    __device__ void operator()(int64_t m, int64_t n, float v, int) const {
+    __device__ Row row(int64_t m, int) const {
         const int ihw = IHp * IWp;
         const int64_t b = m / ihw;
         const int r = (int)(m - b * ihw);
         const int ihp = r / IWp, iwp = r - ihp * IWp;
-        const int64_t off = ((b * g.IH + g.S * ihp + ph) * g.IW + g.S * iwp + pw) * g.Cin + n;
-        dX[off] = Xact[off] > 0.f ? v : 0.f;
+        return ((b * g.IH + g.S * ihp + ph) * g.IW + g.S * iwp + pw) * g.Cin;
     }
+    __device__ void operator()(const Row &r, int n, float v) const { dX[r + n] = Xact[r + n] > 0.f ? v : 0.f; }
 };
 
 int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, const ConvShape &c, hipStream_t s) {

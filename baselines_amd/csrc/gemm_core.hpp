@@ -38,7 +38,8 @@ constexpr int GEMM_THREADS = 256;
 //   image / pixel, a column into tap / channel) runs once per tile or once per slab instead of once per element;
 //   on the vector path it also runs once per kVec elements, which is what keeps the main loop's VALU work below
 //   its MFMA work for the narrow (few output columns) and byte-input products.
-// Epilogue concept: void operator()(int64_t m, int64_t n, float acc, int z) const
+// Epilogue concept: Row row(int64_t m, int z) const — what the output address owes to the row (and the slab);
+//                   void operator()(const Row &, int n, float acc) const
 
 // LDS row pitch: rows lh = 0 / 1 of an operand read must land on different bank halves (pitch = 32 mod 64)
 // when rows are written as vectors; the scalar path keeps the odd pitch that spreads its k-fast writes.
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     constexpr int A_MG = BM / AV, B_NG = BN / BV;       // groups along the contiguous coordinate (vector path)
     constexpr bool A_ROWS_ONCE = AL::kInnerFast;        // which context array is per-element
     typename AL::Row arow[(AV == 1 && A_ROWS_ONCE) ? A_PER : 1];
-    typename AL::Col acol[A_ROWS_ONCE ? 1 : A_PER];
+    typename AL::Col acol[(AV == 1 && A_ROWS_ONCE) ? 1 : A_PER];
     typename BL::Row brow[BL::kInnerFast ? B_PER : 1];
     typename BL::Col bcol[BL::kInnerFast ? 1 : B_PER];
     bool a_ok[(AV == 1 && A_ROWS_ONCE) ? A_PER : 1], b_ok[BL::kInnerFast ? 1 : B_PER];
@@ -103,6 +104,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
             const int64_t m = m0 + tid % BM;
             a_ok[0] = m < M;
             arow[0] = a.row(a_ok[0] ? m : 0);
+#pragma unroll
+            for (int e = 0; e < A_PER; e++) acol[e] = a.col(kbeg + ((tid + e * GEMM_THREADS) / BM) * AV);
         } else {
             const int64_t m = m0 + (tid % A_MG) * AV;
             a_ok[0] = m < M;                             // M is a multiple of AV: a group is all in or all out
@@ -117,6 +120,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
             a_ok[e] = m < M;
             arow[e] = a.row(a_ok[e] ? m : 0);
         }
+        acol[0] = a.col(kbeg + tid % GEMM_BK);
     } else {
         const int64_t m = m0 + tid % BM;
         a_ok[0] = m < M;
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
             b_ok[e] = n < N;
             bcol[e] = b.col(b_ok[e] ? n : 0);
         }
+        brow[0] = b.row(kbeg + tid % GEMM_BK);
     }
 
     // loads slab [k0, k0 + 16); the advancing contexts stand at k0 on entry and at k0 + 16 on exit
@@ -153,11 +158,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
                 const int t = tid + e * GEMM_THREADS;
                 const int64_t k = k0 + (t / BM) * AV;                       // K is a multiple of AV
                 if (t < A_TASKS_ALL && a_ok[0] && k < kend) {
-                    a.at_vec(arow[0], a.col(k), areg[e]);
+                    a.at_vec(arow[0], acol[e], areg[e]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < AV; j++) areg[e][j] = 0.f;
                 }
+                a.advance_col(acol[e], GEMM_BK);
             }
         } else if constexpr (AV > 1) {
 #pragma unroll
@@ -175,9 +181,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
         } else if constexpr (AL::kInnerFast) {
             const int64_t k = k0 + tid % GEMM_BK;
             const bool kok = k < kend;
-            acol[0] = a.col(kok ? k : kbeg);
 #pragma unroll
             for (int e = 0; e < A_PER; e++) areg[e][0] = (kok && a_ok[e]) ? a.at(arow[e], acol[0]) : 0.f;
+            a.advance_col(acol[0], GEMM_BK);
         } else {
 #pragma unroll
             for (int e = 0; e < A_PER; e++) {
@@ -209,9 +215,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
         } else {
             const int64_t k = k0 + tid % GEMM_BK;
             const bool kok = k < kend;
-            brow[0] = b.row(kok ? k : kbeg);
 #pragma unroll
             for (int e = 0; e < B_PER; e++) breg[e][0] = (kok && b_ok[e]) ? b.at(brow[0], bcol[e]) : 0.f;
+            b.advance_row(brow[0], GEMM_BK);
         }
     };
     auto stash = [&]() {
@@ -271,13 +277,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
             }
         }
     }
+    // what an output element's address owes to its row (a division or two for the implicit-GEMM epilogues) is
+    // worked out once per row of the tile and handed round through LDS
+    typedef typename EP::Row EpRow;
+    static_assert(sizeof(EpRow) * BM <= sizeof(float) * GEMM_BK * LDA, "row contexts must fit the A tile");
+    __syncthreads();
+    EpRow *rows = reinterpret_cast<EpRow *>(As);
+    if (tid < BM) rows[tid] = ep.row(m0 + tid < M ? m0 + tid : M - 1, z);
+    __syncthreads();
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
         const int n = n0 + (wn * NB + nb) * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m < M && n < N) ep(m, n, acc[nb][r], z);
+            const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m0 + ml < M && n < N) ep(rows[ml], n, acc[nb][r]);
         }
     }
 }
@@ -399,37 +413,43 @@ __device__ inline float act_grad(float h, int act) {
     return 1.f;
 }
 struct EpiBiasAct {
+    typedef int64_t Row;
     float *C;
     int64_t ldc;
     const float *bias;
     int act;
     int accumulate;
-    __device__ void operator()(int64_t m, int64_t n, float v, int) const {
+    __device__ Row row(int64_t m, int) const { return m * ldc; }
+    __device__ void operator()(const Row &r, int n, float v) const {
         if (bias) v += bias[n];
-        float *d = C + m * ldc + n;
+        float *d = C + r + n;
         if (accumulate) v += *d;
         *d = apply_act(v, act);
     }
 };
 struct EpiActGrad {
+    struct Row { int64_t c, h; };
     float *C;
     int64_t ldc;
     const float *H;
     int64_t ldh;
     int act;
     int accumulate;
-    __device__ void operator()(int64_t m, int64_t n, float v, int) const {
-        if (H) v *= act_grad(H[m * ldh + n], act);
-        float *d = C + m * ldc + n;
+    __device__ Row row(int64_t m, int) const { return Row{m * ldc, m * ldh}; }
+    __device__ void operator()(const Row &r, int n, float v) const {
+        if (H) v *= act_grad(H[r.h + n], act);
+        float *d = C + r.c + n;
         if (accumulate) v += *d;
         *d = v;
     }
 };
 struct EpiSlab {
+    typedef int64_t Row;
     float *C;
     int64_t ldc;
     int64_t zstride;
-    __device__ void operator()(int64_t m, int64_t n, float v, int z) const { C[z * zstride + m * ldc + n] = v; }
+    __device__ Row row(int64_t m, int z) const { return z * zstride + m * ldc; }
+    __device__ void operator()(const Row &r, int n, float v) const { C[r + n] = v; }
 };
 
 }  // namespace ppo2hip
