@@ -23,6 +23,20 @@ int fc_dgrad(const float *dY, int lddy, const float *W, int Kin, int N, const fl
     return launch_gemm(A, B, ep, M, Kin, N, 1, s, "fc_dgrad");
 }
 
+int fc_forward_parts(const float *X, int ldx, const float *W, int M, int N, int K, int nparts, float *parts, hipStream_t s) {
+    RowMajor A{X, ldx};
+    RowMajor B{W, N};
+    EpiSlab ep{parts, N, (int64_t)M * N};
+    return launch_gemm(A, B, ep, M, N, K, nparts, s, "fc_forward_parts");
+}
+
+int fc_dgrad_parts(const float *dY, int lddy, const float *W, int Kin, int N, int M, int nparts, float *parts, hipStream_t s) {
+    RowMajor A{dY, lddy};
+    Transposed B{W, N};
+    EpiSlab ep{parts, Kin, (int64_t)M * Kin};
+    return launch_gemm(A, B, ep, M, Kin, N, nparts, s, "fc_dgrad_parts");
+}
+
 bool wgrad_bias_separately(int Kin);
 
 static int pick_slabs(int64_t S, int64_t tiles) {

@@ -315,7 +315,8 @@ inline int launch_gemm(const AL &a, const BL &b, const EP &ep, int64_t M, int N,
     if (nsplit < 1) nsplit = 1;
     int64_t klen = ceil_div(K > 0 ? K : 1, nsplit);
     klen = ceil_div(klen, GEMM_BK) * GEMM_BK;
-    const bool small_m = M <= 64;
+    // 64-row tiles for short operands, and wherever 128-row tiles would leave most of the 256 CUs without a workgroup
+    const bool small_m = M <= 64 || (M <= 512 && ceil_div(M, 128) * ceil_div(N, 64) * nsplit < 128);
     const bool narrow = !small_m && N <= 32;        // half of a 64-column tile would multiply zeros
     const int BM = small_m ? 64 : 128, BN = narrow ? 32 : 64;
     const int64_t gx = ceil_div(M, BM);

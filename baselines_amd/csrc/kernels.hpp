@@ -22,6 +22,10 @@ int fc_dgrad(const float *dY, int lddy, const float *W, int Kin, int N, const fl
 int fc_wgrad_slabs(const float *X, int ldx, const float *dY, int lddy, int64_t S, int Kin, int N,
                    float *slabs, int max_slabs, int *nslabs, hipStream_t s);
 int wgrad_max_slabs(int64_t S, int Kin, int N);
+// split-k partial products for few-row operands: parts[z][M, N] = X[:, k-slice z] W[k-slice z, :]
+int fc_forward_parts(const float *X, int ldx, const float *W, int M, int N, int K, int nparts, float *parts, hipStream_t s);
+// parts[z][M, Kin] = dY[:, n-slice z] W[:, n-slice z]^T
+int fc_dgrad_parts(const float *dY, int lddy, const float *W, int Kin, int N, int M, int nparts, float *parts, hipStream_t s);
 // true when the bias row is better summed on its own than folded into the product as a row of ones
 bool wgrad_bias_separately(int Kin);
 // row Kin of every slab = column sums of dY over that slab's sample rows
@@ -121,10 +125,17 @@ int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, co
 // ---- LSTM (lstm.hip): element-wise halves of the cell; products go through the GEMM -----
 int lstm_mask(const float *c_prev, const float *h_prev, int64_t prev_stride, const uint8_t *masks, int64_t mask_stride,
               int nenv, int nh, float *cm, float *hm, int64_t out_stride, hipStream_t s);
-int lstm_gates(float *z, int64_t z_stride, const float *cm, int64_t s_stride, int nenv, int nh, float *c, float *h,
-               float *state_out, hipStream_t s);
+// The per-step products (hm wh forward, dz wh^T backward) have few rows, so they are split over k into `parts`
+// partial products [parts][nenv, width] that the element-wise kernel of the same step sums in a fixed order.
+constexpr int kLstmFwdParts = 4, kLstmBwdParts = 8;
+// z rows hold x wx + b; zparts the partial hm wh products.  Also writes the NEXT step's masked states
+// (cm_next = c (1 - m_next), hm_next likewise) when mask_next is given.
+int lstm_gates(float *z, int64_t z_stride, const float *zparts, int nparts, const float *cm, int64_t s_stride, int nenv,
+               int nh, float *c, float *h, float *state_out, const uint8_t *mask_next, int64_t mask_stride, float *cm_next,
+               float *hm_next, hipStream_t s);
+// dhm_parts: partial products of dz_{t+1} wh^T, [nparts][nenv, nh]
 int lstm_gates_bwd(float *gates, int64_t z_stride, const float *c, const float *cm, const float *dh_head,
-                   int64_t s_stride, const float *dhm_next, float *dcm_carry, const uint8_t *mask_next,
+                   int64_t s_stride, const float *dhm_parts, int nparts, float *dcm_carry, const uint8_t *mask_next,
                    int64_t mask_stride, int nenv, int nh, hipStream_t s);
 
 // layer-normalised cell (a2c/utils.py:110-147); see lstm.hip for the buffer meanings

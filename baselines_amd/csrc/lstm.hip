@@ -21,15 +21,27 @@ __global__ void lstm_mask_kernel(const float *__restrict__ c_prev, const float *
     hm[(int64_t)e * out_stride + j] = h_prev[(int64_t)e * prev_stride + j] * keep;
 }
 
-// z rows hold x wx + hm wh + b on entry and the activated gates (i, f, o, u) on exit
-__global__ void lstm_gate_kernel(float *__restrict__ z, int64_t z_stride, const float *__restrict__ cm,
-                                 int64_t s_stride, int nenv, int nh, float *__restrict__ c, float *__restrict__ h,
-                                 float *__restrict__ state_out /* [nenv, 2nh] or null */) {
+// z rows hold x wx + b on entry (plus nparts partial products of hm wh in zparts, summed here in order) and the
+// activated gates (i, f, o, u) on exit.  With mask_next the kernel also prepares the next step's masked states.
+__global__ void lstm_gate_kernel(float *__restrict__ z, int64_t z_stride, const float *__restrict__ zparts, int nparts,
+                                 const float *__restrict__ cm, int64_t s_stride, int nenv, int nh, float *__restrict__ c,
+                                 float *__restrict__ h, float *__restrict__ state_out /* [nenv, 2nh] or null */,
+                                 const uint8_t *__restrict__ mask_next, int64_t mask_stride, float *__restrict__ cm_next,
+                                 float *__restrict__ hm_next) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (int64_t)nenv * nh) return;
     const int e = (int)(g / nh), j = (int)(g - (int64_t)e * nh);
     float *zr = z + (int64_t)e * z_stride;
-    const float i = sigmoidf(zr[j]), f = sigmoidf(zr[nh + j]), o = sigmoidf(zr[2 * nh + j]), u = tanhf(zr[3 * nh + j]);
+    float zv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) zv[q] = zr[q * nh + j];
+    const int64_t part_stride = (int64_t)nenv * 4 * nh;
+    for (int p = 0; p < nparts; p++) {
+        const float *zp = zparts + p * part_stride + (int64_t)e * 4 * nh;
+#pragma unroll
+        for (int q = 0; q < 4; q++) zv[q] += zp[q * nh + j];
+    }
+    const float i = sigmoidf(zv[0]), f = sigmoidf(zv[1]), o = sigmoidf(zv[2]), u = tanhf(zv[3]);
     const float cn = f * cm[(int64_t)e * s_stride + j] + i * u;
     const float hn = o * tanhf(cn);
     zr[j] = i; zr[nh + j] = f; zr[2 * nh + j] = o; zr[3 * nh + j] = u;
@@ -39,13 +51,19 @@ __global__ void lstm_gate_kernel(float *__restrict__ z, int64_t z_stride, const 
         state_out[(int64_t)e * 2 * nh + j] = cn;
         state_out[(int64_t)e * 2 * nh + nh + j] = hn;
     }
+    if (mask_next) {
+        const float keep = mask_next[(int64_t)e * mask_stride] ? 0.f : 1.f;
+        cm_next[(int64_t)e * s_stride + j] = cn * keep;
+        hm_next[(int64_t)e * s_stride + j] = hn * keep;
+    }
 }
 
-// Backward of one step.  dh = dH_head[t] + dhm_next * (1 - m_{t+1}), dc_in = dcm_next * (1 - m_{t+1}).
+// Backward of one step.  dh = dH_head[t] + dhm_next * (1 - m_{t+1}), dc_in = dcm_next * (1 - m_{t+1}), where
+// dhm_next is the sum, in order, of the nparts partial products of dz_{t+1} wh^T.
 // Writes dz over the gate rows and the new (unmasked) dcm carry.
 __global__ void lstm_gate_bwd_kernel(float *__restrict__ gates, int64_t z_stride, const float *__restrict__ c,
                                      const float *__restrict__ cm, const float *__restrict__ dh_head,
-                                     int64_t s_stride, const float *__restrict__ dhm_next,
+                                     int64_t s_stride, const float *__restrict__ dhm_parts, int nparts,
                                      float *__restrict__ dcm_carry, const uint8_t *__restrict__ mask_next,
                                      int64_t mask_stride, int nenv, int nh) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,7 +74,10 @@ __global__ void lstm_gate_bwd_kernel(float *__restrict__ gates, int64_t z_stride
     const int64_t sr = (int64_t)e * s_stride + j, cr = (int64_t)e * nh + j;
     float *zr = gates + (int64_t)e * z_stride;
     const float i = zr[j], f = zr[nh + j], o = zr[2 * nh + j], u = zr[3 * nh + j];
-    const float dh = dh_head[sr] + (mask_next ? dhm_next[cr] * keep : 0.f);
+    float dhm = 0.f;
+    if (mask_next)
+        for (int p = 0; p < nparts; p++) dhm += dhm_parts[(int64_t)p * nenv * nh + cr];
+    const float dh = dh_head[sr] + dhm * keep;
     const float tc = tanhf(c[sr]);
     const float dc = (mask_next ? dcm_carry[cr] * keep : 0.f) + dh * o * (1.f - tc * tc);
     zr[j] = dc * u * i * (1.f - i);
@@ -339,20 +360,21 @@ int lstm_mask(const float *c_prev, const float *h_prev, int64_t prev_stride, con
     return check_launch("lstm_mask_kernel");
 }
 
-int lstm_gates(float *z, int64_t z_stride, const float *cm, int64_t s_stride, int nenv, int nh, float *c, float *h,
-               float *state_out, hipStream_t s) {
+int lstm_gates(float *z, int64_t z_stride, const float *zparts, int nparts, const float *cm, int64_t s_stride, int nenv,
+               int nh, float *c, float *h, float *state_out, const uint8_t *mask_next, int64_t mask_stride, float *cm_next,
+               float *hm_next, hipStream_t s) {
     const int64_t n = (int64_t)nenv * nh;
-    hipLaunchKernelGGL(lstm_gate_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, z, z_stride, cm, s_stride,
-                       nenv, nh, c, h, state_out);
+    hipLaunchKernelGGL(lstm_gate_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, z, z_stride, zparts, nparts, cm,
+                       s_stride, nenv, nh, c, h, state_out, mask_next, mask_stride, cm_next, hm_next);
     return check_launch("lstm_gate_kernel");
 }
 
 int lstm_gates_bwd(float *gates, int64_t z_stride, const float *c, const float *cm, const float *dh_head,
-                   int64_t s_stride, const float *dhm_next, float *dcm_carry, const uint8_t *mask_next,
+                   int64_t s_stride, const float *dhm_parts, int nparts, float *dcm_carry, const uint8_t *mask_next,
                    int64_t mask_stride, int nenv, int nh, hipStream_t s) {
     const int64_t n = (int64_t)nenv * nh;
     hipLaunchKernelGGL(lstm_gate_bwd_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, gates, z_stride, c, cm,
-                       dh_head, s_stride, dhm_next, dcm_carry, mask_next, mask_stride, nenv, nh);
+                       dh_head, s_stride, dhm_parts, nparts, dcm_carry, mask_next, mask_stride, nenv, nh);
     return check_launch("lstm_gate_bwd_kernel");
 }
 

@@ -278,6 +278,7 @@ struct CnnBuf {
     float *RET, *OLDV, *NLP, *ADV;
     float *Y1, *Y2, *Y3, *F, *PI, *VF;
     float *Z, *HM, *CM, *C, *Hs, *S0;          // LSTM: gates [B,4nh], masked prev states, states, gathered initial state
+    float *ZP;                                 // partial products of one step's hm wh, [kLstmFwdParts][nenv, 4nh]
     float *ZX, *ZH, *CN, *RX, *RH, *RC;        // layer-normalised cell: normalised x wx / hm wh / c rows and their 1/std
     float *dPI, *dVF, *dF, *dY3, *dY2, *dY1, *DH, *dhm, *dcm;
     float *DZX, *DZH, *DL;                     // ... gradients w.r.t. the raw products and w.r.t. LN(c)
@@ -297,6 +298,7 @@ static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver 
         w.HM = c.take<float>(B * k.nh); w.CM = c.take<float>(B * k.nh);
         w.C = c.take<float>(B * k.nh); w.Hs = c.take<float>(B * k.nh);
         w.S0 = c.take<float>((int64_t)nenv * 2 * k.nh);
+        w.ZP = c.take<float>((int64_t)kLstmFwdParts * nenv * 4 * k.nh);
         if (k.ln) {
             w.ZX = c.take<float>(B * 4 * k.nh); w.ZH = c.take<float>(B * 4 * k.nh); w.CN = c.take<float>(B * k.nh);
             w.RX = c.take<float>(B); w.RH = c.take<float>(B); w.RC = c.take<float>(B);
@@ -315,7 +317,7 @@ static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver 
     w.dY1 = c.take<float>(B * k.h1 * k.w1 * 32);
     if (k.lstm) {
         w.DH = c.take<float>(B * k.nh);
-        w.dhm = c.take<float>((int64_t)nenv * k.nh); w.dcm = c.take<float>((int64_t)nenv * k.nh);
+        w.dhm = c.take<float>((int64_t)kLstmBwdParts * nenv * k.nh); w.dcm = c.take<float>((int64_t)nenv * k.nh);
         if (k.ln) {
             w.DZX = c.take<float>(B * 4 * k.nh); w.DZH = c.take<float>(B * 4 * k.nh); w.DL = c.take<float>(B * k.nh);
         }
@@ -380,15 +382,16 @@ static int lstm_forward_all(const ppo2hip_policy_desc &d, const Layout &L, const
     // x wx + b for every row at once
     if ((rc = fc_forward(w.F, 512, p + L.off("lstm1/wx"), p + L.off("lstm1/b"), w.Z, 4 * nh, (int)B, 4 * nh, 512, ACT_NONE, false, s))) return rc;
     const float *wh = p + L.off("lstm1/wh");
+    // step 0 masks the gathered initial state; every later step's masked states come out of the step before
+    if ((rc = lstm_mask(w.S0, w.S0 + nh, 2 * nh, masks, T, nenv, nh, w.CM, w.HM, (int64_t)T * nh, s))) return rc;
     for (int t = 0; t < T; t++) {
-        const float *cprev = t == 0 ? w.S0 : w.C + (int64_t)(t - 1) * nh;
-        const float *hprev = t == 0 ? w.S0 + nh : w.Hs + (int64_t)(t - 1) * nh;
-        const int64_t pstride = t == 0 ? 2 * nh : (int64_t)T * nh;
-        if ((rc = lstm_mask(cprev, hprev, pstride, masks + t, T, nenv, nh, w.CM + (int64_t)t * nh, w.HM + (int64_t)t * nh, (int64_t)T * nh, s))) return rc;
-        // z_t += hm_t wh   (rows of step t are T rows apart)
-        if ((rc = fc_forward(w.HM + (int64_t)t * nh, T * nh, wh, nullptr, w.Z + (int64_t)t * 4 * nh, T * 4 * nh, nenv, 4 * nh, nh, ACT_NONE, true, s))) return rc;
-        if ((rc = lstm_gates(w.Z + (int64_t)t * 4 * nh, (int64_t)T * 4 * nh, w.CM + (int64_t)t * nh, (int64_t)T * nh, nenv, nh,
-                             w.C + (int64_t)t * nh, w.Hs + (int64_t)t * nh, t == T - 1 ? state_out : nullptr, s))) return rc;
+        const int64_t o1 = (int64_t)t * nh, o4 = (int64_t)t * 4 * nh;
+        // partial products of hm_t wh (rows of step t are T rows apart), summed into z_t by the gate kernel
+        if ((rc = fc_forward_parts(w.HM + o1, T * nh, wh, nenv, 4 * nh, nh, kLstmFwdParts, w.ZP, s))) return rc;
+        const bool last = t == T - 1;
+        if ((rc = lstm_gates(w.Z + o4, (int64_t)T * 4 * nh, w.ZP, kLstmFwdParts, w.CM + o1, (int64_t)T * nh, nenv, nh, w.C + o1,
+                             w.Hs + o1, last ? state_out : nullptr, last ? nullptr : masks + t + 1, T,
+                             last ? nullptr : w.CM + o1 + nh, last ? nullptr : w.HM + o1 + nh, s))) return rc;
     }
     return 0;
 }
@@ -489,9 +492,9 @@ static int cnn_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
         for (int t = T - 1; t >= 0; t--) {
             const uint8_t *mnext = t == T - 1 ? nullptr : w.MASK + (t + 1);
             if ((rc = lstm_gates_bwd(w.Z + (int64_t)t * 4 * nh, (int64_t)T * 4 * nh, w.C + (int64_t)t * nh, w.CM + (int64_t)t * nh,
-                                     w.DH + (int64_t)t * nh, (int64_t)T * nh, w.dhm, w.dcm, mnext, T, nenv, nh, s))) return rc;
-            // dhm = dz_t wh^T
-            if (t > 0 && (rc = fc_dgrad(w.Z + (int64_t)t * 4 * nh, T * 4 * nh, wh, nh, 4 * nh, nullptr, 0, ACT_NONE, w.dhm, nh, nenv, false, s))) return rc;
+                                     w.DH + (int64_t)t * nh, (int64_t)T * nh, w.dhm, kLstmBwdParts, w.dcm, mnext, T, nenv, nh, s))) return rc;
+            // dhm = dz_t wh^T, as partial products that the step before sums
+            if (t > 0 && (rc = fc_dgrad_parts(w.Z + (int64_t)t * 4 * nh, T * 4 * nh, wh, nh, 4 * nh, nenv, kLstmBwdParts, w.dhm, s))) return rc;
         }
         // Z now holds dz for every row.  wx first: its appended ones-row lands on the start of the (wh, b)
         // block that the next product overwrites.
