@@ -24,6 +24,7 @@ class DataParallel:
         self.group = group
         self.size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._gloo = dist.is_initialized() and dist.get_backend(group) == "gloo"
 
     @property
     def grad_scale(self):
@@ -34,7 +35,7 @@ class DataParallel:
     def _staged(self, t):
         """gloo carries host buffers only: device tensors are staged through the host then
         (test rigs without RCCL, e.g. several ranks sharing one GPU)."""
-        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+        return t.is_cuda and self._gloo
 
     def allreduce_sum_(self, t):
         if self.size > 1:

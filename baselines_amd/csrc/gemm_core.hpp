@@ -43,7 +43,12 @@ constexpr int GEMM_THREADS = 256;
 
 // LDS row pitch: rows lh = 0 / 1 of an operand read must land on different bank halves (pitch = 32 mod 64)
 // when rows are written as vectors; the scalar path keeps the odd pitch that spreads its k-fast writes.
-__host__ __device__ constexpr int lds_pitch(int width, bool vec) { return vec ? (width % 64 == 0 ? width + 32 : width) : width + 1; }
+// Vectors along k written with the k group as the fastest lane index (four lanes cover 64 contiguous bytes of one
+// operand row, sixteen rows per load) need pitch = 4 mod 16 for conflict-free writes: 36 mod 64 serves both but
+// for four lanes of each operand read.
+__host__ __device__ constexpr int lds_pitch(int width, int mode) {
+    return mode == 0 ? width + 1 : mode == 1 ? (width % 64 == 0 ? width + 32 : width) : (width % 64 == 0 ? width + 36 : width + 4);
+}
 
 // WM = number of wave rows, NB = 32-column blocks per wave:
 //   <4, 2>: 128 x 64, each wave 32 x 64;  <2, 1>: 64 x 64, each wave 32 x 32;  <4, 1>: 128 x 32, each wave 32 x 32
@@ -54,7 +59,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     constexpr int BM = 32 * WM;
     constexpr int WN = 4 / WM;              // wave columns
     constexpr int BN = 32 * WN * NB;
-    constexpr int LDA = lds_pitch(BM, AV > 1), LDB = lds_pitch(BN, BV > 1);
+    constexpr bool A_KG_FAST = AL::kInnerFast && AV > 1 && AV < GEMM_BK;   // several k groups per row and slab
+    constexpr int LDA = lds_pitch(BM, AV == 1 ? 0 : A_KG_FAST ? 2 : 1), LDB = lds_pitch(BN, BV > 1 ? 1 : 0);
     // element-wise: elements per thread; vector: tasks (one wide load each) per thread
     constexpr int A_TASKS_ALL = BM * GEMM_BK / AV, B_TASKS_ALL = BN * GEMM_BK / BV;
     constexpr int A_PER = (A_TASKS_ALL + GEMM_THREADS - 1) / GEMM_THREADS;
@@ -86,21 +92,31 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     //   B, kInnerFast : n = lin % BN is the thread's own, k differs with e and slab    (row contexts: advanced)
     //   B, otherwise  : k = lin % 16 is the thread's own, n differs with e             (col contexts: once)
     // vector path (task t = tid + e * 256 is one wide load)
-    //   A, kInnerFast : row m = t % BM is the thread's own (lanes along m: conflict-free LDS writes), the task's
-    //                   k group is t / BM                                               (row context: once)
+    //   A, kInnerFast : one k group per row and slab (AV = 16): row m = t % BM, lanes along m;
+    //                   several (AV = 4): k group t % (16/AV) is the thread's own and fastest over the lanes, so a
+    //                   load instruction touches sixteen rows' 64-byte pieces, not 64 rows' 16-byte pieces; rows t / (16/AV)
     //   A, otherwise  : m group t % (BM/AV), k = t / (BM/AV), advanced from slab to slab (LDS rows written as float4)
     //   B (n-fast)    : n group t % (BN/BV), k = t / (BN/BV), advanced from slab to slab
     constexpr int A_KSTEP = GEMM_THREADS / BM;          // k distance between a thread's elements (A, m-fast mapping)
     constexpr int B_KSTEP = GEMM_THREADS / BN;
     constexpr int A_MG = BM / AV, B_NG = BN / BV;       // groups along the contiguous coordinate (vector path)
     constexpr bool A_ROWS_ONCE = AL::kInnerFast;        // which context array is per-element
-    typename AL::Row arow[(AV == 1 && A_ROWS_ONCE) ? A_PER : 1];
-    typename AL::Col acol[(AV == 1 && A_ROWS_ONCE) ? 1 : A_PER];
+    constexpr int A_KGS = GEMM_BK / AV;
+    typename AL::Row arow[((AV == 1 && A_ROWS_ONCE) || A_KG_FAST) ? A_PER : 1];
+    typename AL::Col acol[((AV == 1 && A_ROWS_ONCE) || A_KG_FAST) ? 1 : A_PER];
     typename BL::Row brow[BL::kInnerFast ? B_PER : 1];
     typename BL::Col bcol[BL::kInnerFast ? 1 : B_PER];
-    bool a_ok[(AV == 1 && A_ROWS_ONCE) ? A_PER : 1], b_ok[BL::kInnerFast ? 1 : B_PER];
+    bool a_ok[((AV == 1 && A_ROWS_ONCE) || A_KG_FAST) ? A_PER : 1], b_ok[BL::kInnerFast ? 1 : B_PER];
     if constexpr (AV > 1) {
-        if constexpr (AL::kInnerFast) {
+        if constexpr (A_KG_FAST) {
+#pragma unroll
+            for (int e = 0; e < A_PER; e++) {
+                const int64_t m = m0 + (tid + e * GEMM_THREADS) / A_KGS;
+                a_ok[e] = m < M;
+                arow[e] = a.row(a_ok[e] ? m : 0);
+            }
+            acol[0] = a.col(kbeg + (tid % A_KGS) * AV);
+        } else if constexpr (AL::kInnerFast) {
             const int64_t m = m0 + tid % BM;
             a_ok[0] = m < M;
             arow[0] = a.row(a_ok[0] ? m : 0);
@@ -152,7 +168,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
 
     // loads slab [k0, k0 + 16); the advancing contexts stand at k0 on entry and at k0 + 16 on exit
     auto fetch = [&](int64_t k0) {
-        if constexpr (AV > 1 && AL::kInnerFast) {
+        if constexpr (A_KG_FAST) {
+            const bool kok = k0 + (tid % A_KGS) * AV < kend;                 // K is a multiple of AV
+#pragma unroll
+            for (int e = 0; e < A_PER; e++) {
+                if (kok && a_ok[e]) {
+                    a.at_vec(arow[e], acol[0], areg[e]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < AV; j++) areg[e][j] = 0.f;
+                }
+            }
+            a.advance_col(acol[0], GEMM_BK);
+        } else if constexpr (AV > 1 && AL::kInnerFast) {
 #pragma unroll
             for (int e = 0; e < A_PER; e++) {
                 const int t = tid + e * GEMM_THREADS;
@@ -224,7 +252,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
 #pragma unroll
         for (int e = 0; e < A_PER; e++) {
             const int lin = tid + e * GEMM_THREADS;
-            if constexpr (AV > 1 && AL::kInnerFast) {
+            if constexpr (A_KG_FAST) {
+                const int kg = lin % A_KGS, ml = lin / A_KGS;
+#pragma unroll
+                for (int j = 0; j < AV; j++) As[(kg * AV + j) * LDA + ml] = areg[e][j];
+            } else if constexpr (AV > 1 && AL::kInnerFast) {
                 if (lin < A_TASKS_ALL) {
                     const int ml = lin % BM, kg = lin / BM;
 #pragma unroll
