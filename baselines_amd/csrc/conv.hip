@@ -176,7 +176,12 @@ struct DgradCol {   // A(m = (b,ih,iw), k = (kh,kw,co)) = dY[b, (ih-kh)/s, (iw-k
 
 struct DgradW {   // B(k = (kh,kw,co), n = ci) = W[kh, kw, ci, co]
     static constexpr bool kInnerFast = false;
-    static constexpr int kVec = 1;
+    static constexpr int kVec = 4;      // four output channels of one tap and input channel
+    int vec_width() const { return aligned16(w) && g.Cout % 4 == 0 ? 4 : 1; }
+    __device__ void at_vec(const TapCol &t, const int &c, float (&o)[4]) const {
+        const float4 v = *(const float4 *)(w + (t.kh * g.KW + t.kw) * g.Cin * g.Cout + t.co + c);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
     typedef TapCol Row;
     typedef int Col;
     const float *w;
@@ -265,7 +270,12 @@ struct DgradColP {   // A(m' = (b, ih', iw'), k' = (kh', kw', co)),  ih = S ih' 
 };
 struct DgradWP {   // B(k' = (kh', kw', co), n = ci) = W[ph + S kh', pw + S kw', ci, co]
     static constexpr bool kInnerFast = false;
-    static constexpr int kVec = 1;
+    static constexpr int kVec = 4;
+    int vec_width() const { return aligned16(w) && g.Cout % 4 == 0 ? 4 : 1; }
+    __device__ void at_vec(const TapCol &t, const int &c, float (&o)[4]) const {
+        const float4 v = *(const float4 *)(w + ((ph + g.S * t.kh) * g.KW + pw + g.S * t.kw) * g.Cin * g.Cout + t.co + c);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
     typedef TapCol Row;
     typedef int Col;
     const float *w;

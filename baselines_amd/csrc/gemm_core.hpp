@@ -60,12 +60,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     constexpr int WN = 4 / WM;              // wave columns
     constexpr int BN = 32 * WN * NB;
     constexpr bool A_KG_FAST = AL::kInnerFast && AV > 1 && AV < GEMM_BK;   // several k groups per row and slab
-    constexpr int LDA = lds_pitch(BM, AV == 1 ? 0 : A_KG_FAST ? 2 : 1), LDB = lds_pitch(BN, BV > 1 ? 1 : 0);
+    constexpr int LDA = lds_pitch(BM, AV == 1 ? 0 : A_KG_FAST ? 2 : 1), LDB = lds_pitch(BN, BV == 1 ? 0 : BL::kInnerFast ? 1 : 2);
     // element-wise: elements per thread; vector: tasks (one wide load each) per thread
     constexpr int A_TASKS_ALL = BM * GEMM_BK / AV, B_TASKS_ALL = BN * GEMM_BK / BV;
     constexpr int A_PER = (A_TASKS_ALL + GEMM_THREADS - 1) / GEMM_THREADS;
     constexpr int B_PER = (B_TASKS_ALL + GEMM_THREADS - 1) / GEMM_THREADS;
-    static_assert(BV == 1 || BL::kInnerFast, "vector loads of B run along n");
     __shared__ __attribute__((aligned(16))) float As[GEMM_BK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[GEMM_BK * LDB];
 
@@ -96,7 +95,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     //                   several (AV = 4): k group t % (16/AV) is the thread's own and fastest over the lanes, so a
     //                   load instruction touches sixteen rows' 64-byte pieces, not 64 rows' 16-byte pieces; rows t / (16/AV)
     //   A, otherwise  : m group t % (BM/AV), k = t / (BM/AV), advanced from slab to slab (LDS rows written as float4)
-    //   B (n-fast)    : n group t % (BN/BV), k = t / (BN/BV), advanced from slab to slab
+    //   B, kInnerFast : n group t % (BN/BV), k = t / (BN/BV), advanced from slab to slab
+    //   B, otherwise  : k group t % (16/BV) fastest over the lanes (as for A), column n = t / (16/BV) the thread's own
     constexpr int A_KSTEP = GEMM_THREADS / BM;          // k distance between a thread's elements (A, m-fast mapping)
     constexpr int B_KSTEP = GEMM_THREADS / BN;
     constexpr int A_MG = BM / AV, B_NG = BN / BV;       // groups along the contiguous coordinate (vector path)
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     constexpr int A_KGS = GEMM_BK / AV;
     typename AL::Row arow[((AV == 1 && A_ROWS_ONCE) || A_KG_FAST) ? A_PER : 1];
     typename AL::Col acol[((AV == 1 && A_ROWS_ONCE) || A_KG_FAST) ? 1 : A_PER];
+    constexpr int B_KGS = GEMM_BK / BV;
     typename BL::Row brow[BL::kInnerFast ? B_PER : 1];
     typename BL::Col bcol[BL::kInnerFast ? 1 : B_PER];
     bool a_ok[((AV == 1 && A_ROWS_ONCE) || A_KG_FAST) ? A_PER : 1], b_ok[BL::kInnerFast ? 1 : B_PER];
@@ -144,7 +145,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
 #pragma unroll
         for (int e = 0; e < A_PER; e++) acol[e] = a.col(kbeg + tid / BM + e * A_KSTEP);
     }
-    if constexpr (BV > 1) {
+    if constexpr (BV > 1 && !BL::kInnerFast) {
+#pragma unroll
+        for (int e = 0; e < B_PER; e++) {
+            const int n = n0 + (tid + e * GEMM_THREADS) / B_KGS;
+            b_ok[e] = n < N && tid + e * GEMM_THREADS < B_TASKS_ALL;
+            bcol[e] = b.col(n < N ? n : 0);
+        }
+        brow[0] = b.row(kbeg + (tid % B_KGS) * BV);
+    } else if constexpr (BV > 1) {
         const int n = n0 + (tid % B_NG) * BV;
         b_ok[0] = n < N;                                 // N is a multiple of BV
         bcol[0] = b.col(b_ok[0] ? n : 0);
@@ -220,7 +229,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
                 a.advance_col(acol[e], GEMM_BK);
             }
         }
-        if constexpr (BV > 1) {
+        if constexpr (BV > 1 && !BL::kInnerFast) {
+            const bool kok = k0 + (tid % B_KGS) * BV < kend;                 // K is a multiple of BV
+#pragma unroll
+            for (int e = 0; e < B_PER; e++) {
+                if (kok && b_ok[e]) {
+                    b.at_vec(brow[0], bcol[e], breg[e]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < BV; j++) breg[e][j] = 0.f;
+                }
+            }
+            b.advance_row(brow[0], GEMM_BK);
+        } else if constexpr (BV > 1) {
 #pragma unroll
             for (int e = 0; e < B_PER; e++) {
                 const int t = tid + e * GEMM_THREADS;
@@ -279,7 +300,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
 #pragma unroll
         for (int e = 0; e < B_PER; e++) {
             const int lin = tid + e * GEMM_THREADS;
-            if constexpr (BV > 1) {
+            if constexpr (BV > 1 && !BL::kInnerFast) {
+                if (lin < B_TASKS_ALL) {
+                    const int kg = lin % B_KGS, nl = lin / B_KGS;
+#pragma unroll
+                    for (int j = 0; j < BV; j++) Bs[(kg * BV + j) * LDB + nl] = breg[e][j];
+                }
+            } else if constexpr (BV > 1) {
                 if (lin < B_TASKS_ALL)
                     *(float4 *)&Bs[(lin / B_NG) * LDB + (lin % B_NG) * BV] = make_float4(breg[e][0], breg[e][1], breg[e][2], breg[e][3]);
             } else {
@@ -358,10 +385,11 @@ inline int launch_gemm(const AL &a, const BL &b, const EP &ep, int64_t M, int N,
     }
     dim3 grid((unsigned)gx, (unsigned)ceil_div(N, BN), (unsigned)nsplit);
     // wide loads where the operand allows them and the coordinate they run along comes in whole groups
-    constexpr int AVmax = AL::kVec, BVmax = BL::kInnerFast ? BL::kVec : 1;
+    constexpr int AVmax = AL::kVec, BVmax = BL::kVec;
+    static_assert(BVmax == 1 || BVmax == 4, "B operands load four floats at a time");
     const bool av = AVmax > 1 && a.vec_width() == AVmax && (AL::kInnerFast ? K % AVmax == 0 : M % AVmax == 0);
     bool bv = false;
-    if constexpr (BVmax > 1) bv = b.vec_width() == BVmax && N % BVmax == 0;
+    if constexpr (BVmax > 1) bv = b.vec_width() == BVmax && (BL::kInnerFast ? N % BVmax == 0 : K % BVmax == 0);
     if constexpr (AVmax > 1 && BVmax > 1) {
         if (av && bv) return launch_gemm_v<AL, BL, EP, AVmax, BVmax>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
     }
