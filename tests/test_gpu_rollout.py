@@ -204,3 +204,49 @@ def test_learn_on_device_env_improves_return(mods):
     late = float(torch.nanmean(t[-80:]).item())
     print("device env: mean episode return %.2f (first two rollouts) -> %.2f (last two)" % (early, late))
     assert late > early + 10.0 and late > -25.0
+
+
+def test_probtypes_consistency(mods):
+    """The reference's own distribution test (baselines/common/distributions.py:259-307) on the device sampler
+    and neglogp kernel, same pdparams and N: the mean negative log-likelihood of the samples equals the
+    entropy, and -H[p] - E_p[log q] equals KL[p, q], each within three standard errors."""
+    hip, lib = mods["hip"], mods["lib"]
+    N = 100000
+    rng = np.random.RandomState(0)
+
+    def set_logstd(spec, logstd):
+        theta = np.zeros(spec.nparams, np.float32)
+        off = next(o for name, o, shp in spec.vars if name == "logstd")
+        theta[off:off + len(logstd)] = logstd
+        return dev(theta)
+
+    # DiagGaussian: pdparam = [mean | logstd] (:263)
+    pd = np.array([-.2, .3, .4, -.5, .1, -.5, .1, 0.8])
+    mean, logstd = pd[:4], pd[4:]
+    spec = hip.PolicySpec(lib.POLICY_MLP, lib.DIST_GAUSSIAN, 4, 1, ob_dim=3, hidden=(64, 64), order=lib.ORDER_UPSTREAM)
+    theta_p = set_logstd(spec, logstd)
+    pi_p = dev(np.repeat(mean[None].astype(np.float32), N, 0))
+    x, nlp_p = hip.sample_actions(spec, theta_p, pi_p, 17, 0)
+    ll = -nlp_p.double().cpu().numpy()
+    ent = np.sum(logstd + 0.5 * np.log(2.0 * np.pi * np.e))                               # :209-210
+    assert abs(ent - (-ll.mean())) < 3 * ll.std() / np.sqrt(N)
+    q = pd + rng.randn(pd.size) * 0.1
+    qm, qls = q[:4], q[4:]
+    llq = -hip.neglogp(spec, set_logstd(spec, qls), dev(np.repeat(qm[None].astype(np.float32), N, 0)), x).double().cpu().numpy()
+    kl = np.sum(qls - logstd + (np.exp(2 * logstd) + (mean - qm) ** 2) / (2.0 * np.exp(2 * qls)) - 0.5)   # :206-208
+    assert abs(kl - (-ent - llq.mean())) < 3 * llq.std() / np.sqrt(N)
+
+    # Categorical: pdparam = logits (:267)
+    logits = np.array([-.2, .3, .5])
+    cspec = hip.PolicySpec(lib.POLICY_MLP, lib.DIST_CATEGORICAL, 3, 1, ob_dim=3, hidden=(64, 64), order=lib.ORDER_UPSTREAM)
+    theta_c = torch.zeros(cspec.nparams, device="cuda")
+    xs, nlp_c = hip.sample_actions(cspec, theta_c, dev(np.repeat(logits[None].astype(np.float32), N, 0)), 23, 0)
+    ll = -nlp_c.double().cpu().numpy()
+    lsm = lambda l: l - l.max() - np.log(np.exp(l - l.max()).sum())
+    p = np.exp(lsm(logits))
+    ent = -(p * lsm(logits)).sum()                                                        # :157-162
+    assert abs(ent - (-ll.mean())) < 3 * ll.std() / np.sqrt(N)
+    ql = logits + rng.randn(3) * 0.1
+    llq = -hip.neglogp(cspec, theta_c, dev(np.repeat(ql[None].astype(np.float32), N, 0)), xs).double().cpu().numpy()
+    kl = (p * (lsm(logits) - lsm(ql))).sum()                                              # :147-156
+    assert abs(kl - (-ent - llq.mean())) < 3 * llq.std() / np.sqrt(N)
