@@ -54,6 +54,8 @@ _SIGS = {
     "ppo2hip_discount_with_dones_f32": (c_int, [_P, _P, _P, c_double, c_int, c_int, _P, _P]),
     "ppo2hip_rms_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ppo2hip_rms_update": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, c_size_t, _P]),
+    "ppo2hip_column_moments": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, _P, c_size_t, _P]),
+    "ppo2hip_add_f64": (c_int, [_P, _P, c_int64, _P]),
     "ppo2hip_normalize_clip": (c_int, [_P, c_int, c_int64, c_int64, _P, _P, c_double, c_double, _P, c_int, _P]),
     "ppo2hip_vecnorm_returns": (c_int, [_P, c_int, c_int64, c_double, _P, _P, c_double, c_double, _P, c_int, _P,
                                         c_size_t, _P]),

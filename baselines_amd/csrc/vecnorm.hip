@@ -148,6 +148,29 @@ __global__ void frame_stack_kernel(W *__restrict__ stacked, const W *__restrict_
     for (int k = 0; k < c; k++) row[keep + k] = o[k];
 }
 
+// Plain column sums and sums of squares (x cast to float64 first), plus the row count: the vector the MPI running
+// statistics all-reduce (baselines/common/mpi_running_mean_std.py:37-42).  One wave per column folds the slabs.
+__global__ __launch_bounds__(64) void moments_fold_kernel(const double *__restrict__ partial, int nslabs, int64_t n,
+                                                          int64_t d, double *__restrict__ out /* [2d + 1] */) {
+    const int64_t c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int s = threadIdx.x; s < nslabs; s += 64) {
+        a += partial[(int64_t)s * 2 * d + c];
+        b += partial[(int64_t)s * 2 * d + d + c];
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (threadIdx.x != 0) return;
+    out[c] = a;
+    out[d + c] = b;
+    if (c == 0) out[2 * d] = (double)n;
+}
+
+__global__ void add_f64_kernel(double *__restrict__ dst, const double *__restrict__ src, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 static int rms_update_impl(const void *x, int x_f64, int64_t n, int64_t d, double *state, void *workspace,
                            size_t workspace_bytes, hipStream_t s) {
     const RmsGrid g = rms_grid(n, d);
@@ -207,6 +230,39 @@ extern "C" int ppo2hip_rms_update(const void *x, int x_f64, int64_t n, int64_t d
     PPO2HIP_REQUIRE(n > 0, "rms_update: empty batch");
     PPO2HIP_REQUIRE(x && state, "rms_update: null pointer");
     return rms_update_impl(x, x_f64, n, d, state, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ppo2hip_column_moments(const void *x, int x_f64, int64_t n, int64_t d, const double *zeros, double *out,
+                                      void *workspace, size_t workspace_bytes, void *stream) {
+    PPO2HIP_REQUIRE(n >= 1 && d >= 1 && d <= 0x7fffffffll, "column_moments: bad shape n=%lld d=%lld", (long long)n, (long long)d);
+    PPO2HIP_REQUIRE(x && zeros && out, "column_moments: null pointer");
+    const RmsGrid g = rms_grid(n, d);
+    Carver cv(workspace, workspace_bytes);
+    double *partial = cv.take<double>((size_t)g.nslabs * 2 * d);
+    if (!cv.ok || !workspace) {
+        set_error("column_moments: workspace too small (%zu bytes given, %zu needed)", workspace_bytes, cv.used());
+        return PPO2HIP_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)g.ctiles, (unsigned)g.nslabs);
+    if (x_f64)
+        hipLaunchKernelGGL(rms_moments_kernel<double>, grid, dim3(kRmsThreads), 0, s, (const double *)x, n, d, zeros, g.cw,
+                           g.rpi, partial);
+    else
+        hipLaunchKernelGGL(rms_moments_kernel<float>, grid, dim3(kRmsThreads), 0, s, (const float *)x, n, d, zeros, g.cw,
+                           g.rpi, partial);
+    int rc = check_launch("rms_moments_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(moments_fold_kernel, dim3((unsigned)d), dim3(64), 0, s, partial, g.nslabs, n, d, out);
+    return check_launch("moments_fold_kernel");
+}
+
+extern "C" int ppo2hip_add_f64(double *dst, const double *src, int64_t n, void *stream) {
+    PPO2HIP_REQUIRE(n >= 0, "add_f64: bad n");
+    if (n == 0) return PPO2HIP_OK;
+    PPO2HIP_REQUIRE(dst && src, "add_f64: null pointer");
+    hipLaunchKernelGGL(add_f64_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    return check_launch("add_f64_kernel");
 }
 
 extern "C" int ppo2hip_normalize_clip(const void *x, int x_f64, int64_t n, int64_t d, const double *mean,

@@ -154,6 +154,33 @@ def rms_update(state, x, workspace=None):
     return workspace
 
 
+def column_moments(x, zeros=None, workspace=None):
+    """[x.sum(0) | (x*x).sum(0) | len(x)] in float64 on the device, for x [n, ...]."""
+    x = _float_dev(x, "x")
+    n = x.shape[0]
+    d = x.numel() // n if n else 0
+    if n < 1 or d < 1:
+        raise ValueError("x must hold at least one row")
+    if zeros is None or zeros.numel() < d:
+        zeros = torch.zeros(d, dtype=torch.float64, device=x.device)
+    need = lib.ppo2hip_rms_workspace_bytes(n, d)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    out = torch.empty(2 * d + 1, dtype=torch.float64, device=x.device)
+    check(lib.ppo2hip_column_moments(_ptr(x), int(x.dtype == torch.float64), n, d, _ptr(zeros), _ptr(out), _ptr(workspace),
+                                     workspace.numel(), _stream()), "column_moments")
+    return out
+
+
+def add_f64_(dst, src):
+    _dev(dst, torch.float64, "dst")
+    _dev(src, torch.float64, "src")
+    if dst.numel() != src.numel():
+        raise ValueError("dst and src differ in size")
+    check(lib.ppo2hip_add_f64(_ptr(dst), _ptr(src), dst.numel(), _stream()), "add_f64")
+    return dst
+
+
 def normalize_clip(x, state, epsilon, clip, center=True, out_dtype=torch.float32):
     """clip((x - mean) / sqrt(var + epsilon), -clip, clip) with the statistics in ``state``."""
     x = _float_dev(x, "x")

@@ -88,6 +88,15 @@ size_t ppo2hip_rms_workspace_bytes(int64_t n, int64_t d);
 int ppo2hip_rms_update(const void *x, int x_f64, int64_t n, int64_t d, double *state, void *workspace,
                        size_t workspace_bytes, void *stream);
 
+/* The vector the MPI running statistics exchange, baselines/common/mpi_running_mean_std.py:37-42:
+ * out = [ x.sum(0) | square(x).sum(0) | len(x) ] in float64 (x cast to float64 first).
+ *   x [n, d] float32/float64, n >= 1;  zeros : device double[d] of zeros (the shift of the shared
+ *   moments kernel);  out : device double[2d + 1];  workspace : ppo2hip_rms_workspace_bytes(n, d) */
+int ppo2hip_column_moments(const void *x, int x_f64, int64_t n, int64_t d, const double *zeros, double *out,
+                           void *workspace, size_t workspace_bytes, void *stream);
+/* dst += src over n doubles: the assign_add of the all-reduced totals (:29-32). */
+int ppo2hip_add_f64(double *dst, const double *src, int64_t n, void *stream);
+
 /* clip((x - mean) / sqrt(var + epsilon), -clip, clip), the filter of VecNormalize._obfilt,
  * baselines/common/vec_env/vec_normalize.py:37; mean NULL = no centring (the reward filter, :31).
  *   x [n, d] float32/float64; mean, var : device double[d]; out [n, d] float32 or float64 */

@@ -76,3 +76,33 @@ class FrameStack:
                 self.stackedobs[i] = 0
         self.stackedobs[..., -obs.shape[-1]:] = obs
         return self.stackedobs
+
+
+class MpiRunningMeanStd:
+    """``baselines/common/mpi_running_mean_std.py:4-43`` with the all-reduce as a hook: ``allreduce(vec)``
+    returns the sum of ``vec`` over the ranks (identity for one process)."""
+
+    def __init__(self, epsilon=1e-2, shape=(), allreduce=None):
+        self.shape = tuple(shape)
+        self._sum = np.zeros(self.shape, 'float64')
+        self._sumsq = np.full(self.shape, epsilon, 'float64')
+        self._count = np.float64(epsilon)
+        self.allreduce = allreduce or (lambda v: v)
+
+    def update(self, x):
+        x = np.asarray(x).astype('float64')                                               # :37
+        n = int(np.prod(self.shape))
+        addvec = np.concatenate([x.sum(axis=0).ravel(), np.square(x).sum(axis=0).ravel(),
+                                 np.array([len(x)], dtype='float64')])                    # :40
+        tot = self.allreduce(addvec)
+        self._sum = self._sum + tot[0:n].reshape(self.shape)
+        self._sumsq = self._sumsq + tot[n:2 * n].reshape(self.shape)
+        self._count = self._count + tot[2 * n]
+
+    @property
+    def mean(self):
+        return (self._sum / self._count).astype(np.float32)                               # :25
+
+    @property
+    def std(self):
+        return np.sqrt(np.maximum((self._sumsq / self._count).astype(np.float32) - np.square(self.mean), np.float32(1e-2)))

@@ -88,3 +88,73 @@ def test_two_ranks_reproduce_single_process_update():
 def _vars():
     from baselines_amd import _lib, hip
     return hip.PolicySpec(_lib.POLICY_MLP, _lib.DIST_GAUSSIAN, A, 1, ob_dim=D, hidden=(64, 64), order=_lib.ORDER_UPSTREAM).vars
+
+
+# ---- running statistics exchanged over the data-parallel group -----------------------------------------
+def _rms_data(rank):
+    rng = np.random.RandomState(0)
+    p = [rng.randn(3, 2), rng.randn(4, 2), rng.randn(5, 2)]
+    q = [rng.randn(6, 2) * 3 + 1, rng.randn(7, 2) * 3 + 1, rng.randn(8, 2) * 3 + 1]
+    return (p, q)[rank], p + q
+
+
+def _rms_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from baselines_amd.common.mpi_adam import DataParallel
+    from baselines_amd.common.mpi_running_mean_std import RunningMeanStd
+    rms = RunningMeanStd(epsilon=0.0, shape=(2,), comm=DataParallel("mpi"))
+    mine, _ = _rms_data(rank)
+    for x in mine:
+        rms.update(x)
+    if rank == 0:
+        out.put((rms.mean, rms.std, rms.state.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mpi_running_mean_std_two_ranks():
+    """The reference's own distributed check (baselines/common/mpi_running_mean_std.py:85-107): two ranks fed
+    different data end with the statistics of the concatenated data."""
+    from oracle import envwrap
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_rms_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    mean, std, state = out.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    _, everything = _rms_data(0)
+    allx = np.concatenate(everything)
+    # the reference compares with allclose against mean / std of the whole; std floors its variance at 1e-2
+    assert np.allclose(mean, allx.mean(0)) and np.allclose(std, np.sqrt(np.maximum(allx.var(0), 1e-2)), atol=1e-6)
+    o = envwrap.MpiRunningMeanStd(epsilon=0.0, shape=(2,))
+    o.update(allx)
+    np.testing.assert_allclose(state, np.concatenate([o._sum, o._sumsq, [o._count]]), rtol=1e-13)
+
+
+def test_mpi_running_mean_std_single_process():
+    """:46-63 of the same file: three updates equal one pass; totals against the oracle to float64 rounding,
+    mean / std (float32 in the reference's graph) exactly where the totals agree."""
+    from baselines_amd.common.mpi_running_mean_std import RunningMeanStd
+    from oracle import envwrap
+    rng = np.random.RandomState(1)
+    for shape in ((), (2,), (5, 3)):
+        xs = [(rng.randn(*((n,) + shape)) * 2 + 0.5).astype(np.float32 if n != 4 else np.float64) for n in (3, 4, 500)]
+        rms, o = RunningMeanStd(shape=shape), envwrap.MpiRunningMeanStd(shape=shape)
+        for x in xs:
+            rms.update(x)
+            o.update(x)
+        st = rms.state.cpu().numpy()
+        np.testing.assert_allclose(st, np.concatenate([o._sum.ravel(), o._sumsq.ravel(), [o._count]]), rtol=1e-13)
+        np.testing.assert_allclose(rms.mean, o.mean, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(rms.std, o.std, rtol=1e-6)
+        assert rms.mean.dtype == np.float32 and rms.mean.shape == shape
