@@ -304,7 +304,28 @@ def main():
     torch.cuda.synchronize()
     gae_ms = e0.elapsed_time(e1) / reps
     assert torch.equal(outs[0], ro.advs_gae) and torch.equal(outs[1], ro.returns)
-    grad_ms = float(np.mean([a.elapsed_time(b) for a, b in events["grad"]]))
+    # median over the minibatches: the first evaluation of an epoch can sit behind the index upload, which is not
+    # launch time
+    grad_ms = float(np.median([a.elapsed_time(b) for a, b in events["grad"]]))
+
+    # what this card delivers on a plain device copy and on the library's fp32 GEMM, for reading the fractions below
+    # against achievable rather than nominal peaks
+    def timed(fn, reps):
+        fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e-3
+    src = torch.empty(1 << 28, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    copy_gbs = 2 * src.numel() * 4 / timed(lambda: dst.copy_(src), 10) / 1e9
+    del dst
+    ga, gb = src[:8192 * 8192].view(8192, 8192), src[8192 * 8192:2 * 8192 * 8192].view(8192, 8192)
+    sgemm_tf = 2 * 8192 ** 3 / timed(lambda: torch.matmul(ga, gb), 5) / 1e12
+    del src, ga, gb
 
     if rank == 0:
         flops_mb = (cnn_flops_per_sample(cfg["hwc"], A, cfg.get("nlstm", 0)) if image else dense_flops_per_sample(D, cfg["hidden"], A, R)) * B
@@ -339,6 +360,8 @@ def main():
                              "unit": "GB/s", "frac": gae_gbs / HBM_PEAK_GBS, "bytes_per_launch": gae_bytes,
                              "traffic": measured_traffic(args.workload, "ppo2hip::gae_tiled_kernel"),
                              "ms_per_launch": gae_ms},
+            "device_measured": {"copy_gbs": copy_gbs, "library_sgemm_tflops": sgemm_tf,
+                                "note": "1 GiB device-to-device copy (read + write) and an 8192^3 fp32 torch.matmul on this card"},
             "losses": [float(x) for x in losses],
         }
         if world == 1 and not args.no_cpu_baseline:
