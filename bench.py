@@ -304,6 +304,36 @@ def main():
     torch.cuda.synchronize()
     gae_ms = e0.elapsed_time(e1) / reps
     assert torch.equal(outs[0], ro.advs_gae) and torch.equal(outs[1], ro.returns)
+
+    # the same kernel family on a rollout large enough to be bandwidth- rather than latency-bound: the 65536-env x
+    # 128-step rollout of the env-sharded configuration, whole, on this one GPU (R = 1)
+    def gae_large():
+        Tl, El = 128, 65536
+        gen = torch.Generator(device=device)
+        gen.manual_seed(3)
+        rw = torch.randn(Tl, El, 1, generator=gen, device=device)
+        vl = torch.randn(Tl, El, 1, generator=gen, device=device)
+        dn = (torch.rand(Tl, El, generator=gen, device=device) < 0.005).to(torch.uint8)
+        lv = torch.randn(El, 1, generator=gen, device=device)
+        ld = torch.zeros(El, dtype=torch.uint8, device=device)
+        o = [torch.empty_like(rw) for _ in range(3)]
+        g1 = (ctypes.c_double * 1)(0.99)
+        call = lambda: check(lib.ppo2hip_gae_f32(ptr(rw), ptr(vl), ptr(dn), ptr(lv), ptr(ld), g1, 0.95, Tl, El, 1, ptr(o[0]),
+                                                 ptr(o[1]), ptr(o[2]), stream), "gae")
+        call()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.empty(64 << 20, device=device).normal_()
+        a.record()
+        for _ in range(reps):
+            call()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        nbytes = Tl * El * 17 + El * 5
+        return {"bound": "hbm", "kernel": "gae_kernel<8>", "workload": "65536 envs x 128 steps, R=1 (configs[3], whole, on one GPU)",
+                "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": nbytes, "ms_per_launch": ms}
+    gae_large_roofline = gae_large() if rank == 0 else None
     # median over the minibatches: the first evaluation of an epoch can sit behind the index upload, which is not
     # launch time
     grad_ms = float(np.median([a.elapsed_time(b) for a, b in events["grad"]]))
@@ -360,6 +390,7 @@ def main():
                              "unit": "GB/s", "frac": gae_gbs / HBM_PEAK_GBS, "bytes_per_launch": gae_bytes,
                              "traffic": measured_traffic(args.workload, "ppo2hip::gae_tiled_kernel"),
                              "ms_per_launch": gae_ms},
+            "gae_roofline_large": gae_large_roofline,
             "device_measured": {"copy_gbs": copy_gbs, "library_sgemm_tflops": sgemm_tf,
                                 "note": "1 GiB device-to-device copy (read + write) and an 8192^3 fp32 torch.matmul on this card"},
             "losses": [float(x) for x in losses],
