@@ -143,3 +143,30 @@ class DevicePointVecEnv:
 
     def close(self):
         pass
+
+
+class IdentityVecEnv:
+    """`nenvs` copies of the reference's IdentityEnv (baselines/common/identity_env.py:5-30): the state is a
+    random integer in [0, dim), the reward is 1 when the action repeats it, episodes never end.  The
+    observation is the one-hot encoding the reference's input layer builds for a Discrete observation space."""
+
+    def __init__(self, nenvs, dim, seed=0):
+        self.num_envs, self.dim = nenvs, dim
+        self.observation_space = Box(0.0, 1.0, shape=(dim,), dtype=np.float32)
+        self.action_space = Discrete(dim)
+        self.rng = np.random.RandomState(seed)
+        self.state = np.zeros(nenvs, np.int64)
+
+    def _obs(self):
+        self.state = self.rng.randint(0, self.dim, size=self.num_envs)
+        return np.eye(self.dim, dtype=np.float32)[self.state]
+
+    def reset(self):
+        return self._obs()
+
+    def step(self, actions):
+        rew = (np.asarray(actions).ravel() == self.state).astype(np.float32)
+        return self._obs(), rew, np.zeros(self.num_envs, bool), [{} for _ in range(self.num_envs)]
+
+    def close(self):
+        pass

@@ -314,3 +314,24 @@ def test_recurrent_update_matches_oracle(mods):
                 for (name, _, _), g in zip(model.spec.vars, model.arena.get_list()))
     print("recurrent two-epoch parameter diff vs oracle: %.3e" % worst)
     assert worst <= 1e-5
+
+
+def test_identity_env_is_learnt(mods):
+    """The reference's integration test (baselines/common/test_identity.py:14-44): ppo2.learn with lr=1e-3,
+    nsteps=128 worth of samples per update, ent_coef=0.01 on IdentityEnv(10) for 50 000 steps, then more than
+    90 % reward over 1000 trials.  Four envs x 32 steps stand for the reference's one env x 128 steps."""
+    pol, ppo2, envs = mods["policies"], mods["ppo2"], mods["envs"]
+    from baselines_amd import logger
+    logger.configure(quiet=True)
+    pol.reset_scopes()
+    pol.set_sample_seed(0)
+    np.random.seed(0)
+    env = envs.IdentityVecEnv(4, 10, seed=0)
+    model = ppo2.learn(policy=pol.MlpPolicy64, env=env, nsteps=32, total_timesteps=50000, ent_coef=0.01, lr=1e-3,
+                       return_model=True, log_interval=10 ** 9)
+    obs, total = env.reset(), 0.0
+    for _ in range(250):
+        obs, rew, _, _ = env.step(model.step(obs)[0])
+        total += rew.sum()
+    print("identity env: %.1f %% reward after 50 000 steps" % (total / 10.0))
+    assert total > 0.9 * 1000
