@@ -240,4 +240,29 @@ int neglogp_rows(int dist, int ac_dim, const float *pi, const float *logstd, con
     return check_launch("neglogp_kernel");
 }
 
+// out[c] = scale * sum over rows of rows[r * stride + c], c < ncols <= 16: the mean of the per-minibatch loss rows
+// (np.mean(mblossvals, axis=0), baselines/ppo2/ppo2.py:139), float64 sums in a fixed order.
+__global__ __launch_bounds__(256) void row_mean_kernel(const float *__restrict__ rows, int nrows, int stride, int ncols,
+                                                       double scale, float *__restrict__ out) {
+    __shared__ double red[16][4];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;          // 16 row groups x 16 columns
+    double s = 0.0;
+    if (c < ncols)
+        for (int r = g; r < nrows; r += 16) s += (double)rows[(int64_t)r * stride + c];
+    // fold the 16 row groups: first within a wave (4 groups per wave), then across the 4 waves
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if ((threadIdx.x & 63) < 16) red[c][threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x < ncols) out[threadIdx.x] = (float)(scale * ((red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3])));
+}
+
 }  // namespace ppo2hip
+
+extern "C" int ppo2hip_row_mean(const float *rows, int nrows, int stride, int ncols, double scale, float *out, void *stream) {
+    using namespace ppo2hip;
+    PPO2HIP_REQUIRE(nrows >= 1 && ncols >= 1 && ncols <= 16 && stride >= ncols, "row_mean: bad shape");
+    PPO2HIP_REQUIRE(rows && out, "row_mean: null pointer");
+    hipLaunchKernelGGL(row_mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, nrows, stride, ncols, scale, out);
+    return check_launch("row_mean_kernel");
+}

@@ -643,6 +643,18 @@ def ppo_epoch(spec, loss_desc, params, grads, m, v, rollout, idx, nbatch_train, 
                                 _stream()), "ppo_epoch")
 
 
+def row_mean(rows, nrows, ncols, scale=None):
+    """scale * column sums of the first ``nrows`` rows and ``ncols`` columns of a float32 [*, stride] tensor
+    (default scale 1/nrows: the mean)."""
+    rows = _dev(rows, torch.float32, "rows")
+    if rows.dim() != 2 or nrows < 1 or nrows > rows.shape[0] or not 1 <= ncols <= min(16, rows.shape[1]):
+        raise ValueError("row_mean: bad shape")
+    out = torch.empty(ncols, dtype=torch.float32, device=rows.device)
+    check(lib.ppo2hip_row_mean(_ptr(rows), int(nrows), int(rows.shape[1]), int(ncols),
+                               float(1.0 / nrows if scale is None else scale), _ptr(out), _stream()), "row_mean")
+    return out
+
+
 def gemm(A, B):
     A = _dev(A, torch.float32, "A")
     B = _dev(B, torch.float32, "B")

@@ -310,11 +310,10 @@ class Model(object):
             elif more_updates:
                 self._begin_index_job(pp, noptepochs)
                 self._pp_ahead = True
-        out = self._losses[:total, :5].double().sum(dim=0) / total
+        # mean of the loss rows (baselines/ppo2/ppo2.py:139); over the ranks too: 1/size folded in before the SUM
+        out = hip.row_mean(self._losses, total, 5, 1.0 / (total * (comm.size if comm is not None else 1)))
         if comm is not None:
             comm.allreduce_sum_(out)
-            out = out / comm.size
-        out = out.float()
         queued = torch.cuda.Event()
         queued.record(main)
         inflight.append(queued)
@@ -364,9 +363,9 @@ class Model(object):
                 row += 1
         if not self._own_stream:
             self._shuffler.release_numpy()
-        out = self._losses[:total, :5].double().sum(dim=0) / total
+        out = hip.row_mean(self._losses, total, 5)
         comm.allreduce_sum_(out)       # per-rank rows are shares of the global means
-        return out.float()
+        return out
 
     # ------------------------------------------------------------------ misc surface
     def get_values(self, obs):

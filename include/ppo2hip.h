@@ -335,6 +335,11 @@ int ppo2hip_ppo_epoch(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *
                       double epsilon, double max_grad_norm, float *losses, void *workspace,
                       size_t workspace_bytes, void *adam_scratch, void *stream);
 
+/* out[c] = scale * sum_r rows[r*stride + c] for c < ncols (<= 16): the mean of the per-minibatch
+ * loss rows that learn reports, baselines/ppo2/ppo2.py:139 (scale = 1/nrows; data-parallel runs
+ * fold 1/size in and SUM-all-reduce the result).  float64 sums, fixed order. */
+int ppo2hip_row_mean(const float *rows, int nrows, int stride, int ncols, double scale, float *out, void *stream);
+
 /* Plain fp32 GEMM on the MFMA path, exposed for tests: C[M,N] = A[M,K] * B[K,N] (row-major). */
 int ppo2hip_gemm_f32(const float *A, const float *B, float *C, int M, int N, int K, void *stream);
 

@@ -207,3 +207,13 @@ def test_add_vtarg_and_adv(hip, golden):
     a64, r64 = scan.gae_single_env_f64(seg["rew"], seg["vpred"], seg["new"], seg["nextvpred"], 0.99, 0.95)
     np.testing.assert_array_equal(seg["adv"], a64)
     np.testing.assert_array_equal(seg["tdlamret"], r64)
+
+
+@pytest.mark.parametrize("nrows,ncols", [(1, 5), (16, 5), (64, 5), (1000, 8), (37, 16)])
+def test_row_mean(hip, nrows, ncols):
+    rng = np.random.RandomState(nrows)
+    rows = (rng.randn(nrows + 3, 16) * 10).astype(np.float32)
+    got = hip.row_mean(dev(rows), nrows, ncols).cpu().numpy()
+    np.testing.assert_allclose(got, rows[:nrows, :ncols].astype(np.float64).mean(0), rtol=2e-7, atol=1e-7)
+    got = hip.row_mean(dev(rows), nrows, ncols, scale=0.5).cpu().numpy()
+    np.testing.assert_allclose(got, 0.5 * rows[:nrows, :ncols].astype(np.float64).sum(0), rtol=2e-7, atol=1e-6)
