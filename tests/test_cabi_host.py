@@ -213,3 +213,16 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(d, f)
                 assert "oracle/" not in text and "oracle." not in text, os.path.join(d, f)
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 on its own, with no C++ or HIP type in it."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this machine")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "ppo2hip.h"\nint main(void) { return ppo2hip_version() == 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], check=True)
