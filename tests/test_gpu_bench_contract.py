@@ -1,0 +1,30 @@
+"""bench.py prints ONE JSON line with the agreed keys (short run, CPU baseline leg skipped).  GPU only."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         cwd=ROOT, check=True, capture_output=True, text=True, timeout=280).stdout
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "configs[1]" in d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None or r["traffic"] > 0
+    g = d["gae_roofline"]
+    assert g["bound"] == "hbm" and g["unit"] == "GB/s" and 0 < g["frac"] < 1
+    assert d["value"] > 1e6 and abs(d["value"] - 524288 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
