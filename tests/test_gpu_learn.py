@@ -335,3 +335,45 @@ def test_identity_env_is_learnt(mods):
         total += rew.sum()
     print("identity env: %.1f %% reward after 50 000 steps" % (total / 10.0))
     assert total > 0.9 * 1000
+
+
+def test_checkpoint_interchange(mods, tmp_path):
+    """save / load / load_value (baselines/ppo2/common_functions.py:115-157): a joblib list of the variables in
+    creation order (13 arrays for the fork's MlpPolicy), readable back with and without the value variables."""
+    import joblib
+    sp, pol, cf = mods["spaces"], mods["policies"], mods["cf"]
+    ob_space, ac_space = sp.Box(-1, 1, shape=(11,)), sp.Box(-1, 1, shape=(3,))
+    kw = dict(policy=pol.MlpPolicy, ob_space=ob_space, ac_space=ac_space, nbatch_act=4, nbatch_train=16, nsteps=4, ent_coef=0.0,
+              vf_coef=0.5, max_grad_norm=0.5)
+    pol.reset_scopes()
+    np.random.seed(3)
+    a = cf.Model(**kw)
+    path, base = str(tmp_path / "00001"), str(tmp_path / "00000")
+    a.save(path, base)
+    ps = joblib.load(path)
+    assert isinstance(ps, list) and len(ps) == 13 and len(joblib.load(base)) == 13
+    names = [n for n, _, _ in a.spec.vars]
+    assert [tuple(p.shape) for p in ps] == [tuple(s) for _, _, s in a.spec.vars]
+    # creation order of baselines/ppo2/policies.py:139-150: actor trunk, logstd, value trunk
+    assert names == ["pi_fc1/w", "pi_fc1/b", "pi_fc2/w", "pi_fc2/b", "pi/w", "pi/b", "logstd",
+                     "vf_fc1/w", "vf_fc1/b", "vf_fc2/w", "vf_fc2/b", "vf/w", "vf/b"]
+    assert ps[6].shape == (1, 3) and ps[0].shape == (11, 256) and ps[11].shape == (128, 5)
+    theta_a = a.arena.theta.cpu().numpy().copy()
+
+    pol.reset_scopes()
+    np.random.seed(4)
+    b = cf.Model(**kw)
+    theta_b0 = b.arena.theta.cpu().numpy().copy()
+    assert not np.array_equal(theta_a, theta_b0)
+    is_vf = np.zeros(theta_a.size, bool)
+    for n, off, shp in b.spec.vars:
+        if n.find("vf") != -1:
+            is_vf[off:off + int(np.prod(shp))] = True
+    b.load(path, load_value=False)                     # everything but the value variables (:126-128)
+    t = b.arena.theta.cpu().numpy()
+    assert np.array_equal(t[~is_vf], theta_a[~is_vf]) and np.array_equal(t[is_vf], theta_b0[is_vf])
+    b.load_value(path)                                 # only the value variables (:149-151)
+    assert np.array_equal(b.arena.theta.cpu().numpy(), theta_a)
+    b.arena.theta.zero_()
+    b.load(path)
+    assert np.array_equal(b.arena.theta.cpu().numpy(), theta_a)
