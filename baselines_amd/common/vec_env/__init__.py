@@ -11,6 +11,8 @@ class VecEnvWrapper(object):
         self.observation_space = observation_space or venv.observation_space
         self.action_space = action_space or venv.action_space
         self._pending = None
+        # an env that lives in HBM stays one under its wrappers: tensors in, tensors out
+        self.device_resident = bool(getattr(venv, "device_resident", False))
 
     def step_async(self, actions):
         if hasattr(self.venv, "step_async"):

@@ -250,3 +250,24 @@ def test_probtypes_consistency(mods):
     llq = -hip.neglogp(cspec, theta_c, dev(np.repeat(ql[None].astype(np.float32), N, 0)), xs).double().cpu().numpy()
     kl = (p * (lsm(logits) - lsm(ql))).sum()                                              # :147-156
     assert abs(kl - (-ent - llq.mean())) < 3 * llq.std() / np.sqrt(N)
+
+
+def test_learn_through_device_wrappers(mods):
+    """VecNormalize around an env that lives in HBM: observations and rewards are filtered on the device, the
+    rollout loop stays device-resident, and learning still solves the task (returns are the env's own,
+    unnormalised)."""
+    envs, pol, ppo2 = mods["envs"], mods["policies"], mods["ppo2"]
+    from baselines_amd.common.vec_env.vec_normalize import VecNormalize
+    pol.reset_scopes()
+    np.random.seed(1)
+    pol.set_sample_seed(2)
+    inner = envs.DevicePointVecEnv(256, dim=2, horizon=20, seed=3)
+    env = VecNormalize(inner)
+    assert env.device_resident
+    ppo2.learn(policy=pol.MlpPolicy64, env=env, nsteps=40, total_timesteps=256 * 40 * 40, ent_coef=0.0, lr=1e-3,
+               nminibatches=4, noptepochs=4, cliprange=0.2, log_interval=1000)
+    t = torch.stack(inner.finished_returns)
+    early, late = float(torch.nanmean(t[:80]).item()), float(torch.nanmean(t[-80:]).item())
+    print("device env under VecNormalize: mean episode return %.2f -> %.2f" % (early, late))
+    assert late > early + 10.0 and late > -25.0
+    assert env.ob_rms.count > 256 * 40 * 39 and abs(float(env.ob_rms.var.mean())) > 0.0
