@@ -217,3 +217,24 @@ def test_row_mean(hip, nrows, ncols):
     np.testing.assert_allclose(got, rows[:nrows, :ncols].astype(np.float64).mean(0), rtol=2e-7, atol=1e-7)
     got = hip.row_mean(dev(rows), nrows, ncols, scale=0.5).cpu().numpy()
     np.testing.assert_allclose(got, 0.5 * rows[:nrows, :ncols].astype(np.float64).sum(0), rtol=2e-7, atol=1e-6)
+
+
+@pytest.mark.parametrize("offa,offb", [(0, 0), (1, 0), (0, 3), (2, 1)])
+def test_gemm_unaligned_operands_take_the_element_path(hip, offa, offb):
+    """Operands whose first element is not 16-byte aligned cannot use the wide loads; the product must not
+    depend on which path ran."""
+    rng = np.random.RandomState(7)
+    M, N, K = 200, 96, 64
+    A = rng.randn(M, K).astype(np.float32)
+    B = rng.randn(K, N).astype(np.float32)
+    bufa = torch.zeros(M * K + 8, device="cuda")
+    bufb = torch.zeros(K * N + 8, device="cuda")
+    a = bufa[offa:offa + M * K].view(M, K)
+    b = bufb[offb:offb + K * N].view(K, N)
+    a.copy_(torch.from_numpy(A))
+    b.copy_(torch.from_numpy(B))
+    assert a.data_ptr() % 16 == 4 * offa and b.data_ptr() % 16 == 4 * offb
+    C = hip.gemm(a, b).cpu().numpy()
+    ref = hip.gemm(dev(A), dev(B)).cpu().numpy()          # aligned: wide loads
+    np.testing.assert_array_equal(C, ref)                  # same fma chain per output element either way
+    np.testing.assert_allclose(C, A.astype(np.float64) @ B.astype(np.float64), rtol=0, atol=2e-5)
