@@ -61,6 +61,9 @@ _SIGS = {
                                         c_size_t, _P]),
     "ppo2hip_frame_stack": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, _P]),
     "ppo2hip_sample_actions": (c_int, [POINTER(PolicyDesc), _P, _P, c_int64, c_uint64, c_uint64, c_int, _P, _P, _P, _P]),
+    "ppo2hip_act_workspace_bytes": (c_size_t, [POINTER(PolicyDesc), c_int64]),
+    "ppo2hip_act_step": (c_int, [POINTER(PolicyDesc), _P, _P, c_int64, _P, _P, c_uint64, c_uint64, c_int, _P, _P, _P, _P, _P,
+                                 c_size_t, _P]),
     "ppo2hip_done_bootstrap": (c_int, [_P, _P, _P, POINTER(c_double), c_int64, c_int, _P]),
     "ppo2hip_row_mean": (c_int, [_P, c_int, c_int, c_int, c_double, _P, _P]),
     "ppo2hip_discount": (c_int, [_P, c_int, _P, c_double, c_int, c_int64, _P, c_int, _P]),

@@ -651,6 +651,29 @@ extern "C" int ppo2hip_sample_actions(const ppo2hip_policy_desc *desc, const flo
                        (hipStream_t)stream);
 }
 
+extern "C" size_t ppo2hip_act_workspace_bytes(const ppo2hip_policy_desc *desc, int64_t B) {
+    if (!desc || B < 0) return 0;
+    return align_up(ppo2hip_forward_workspace_bytes(desc, B), 256) + align_up((size_t)B * (size_t)desc->ac_dim * sizeof(float), 256);
+}
+
+extern "C" int ppo2hip_act_step(const ppo2hip_policy_desc *desc, const float *params, const void *obs, int64_t B,
+                                const uint8_t *masks, const float *states_in, uint64_t seed, uint64_t step,
+                                int deterministic, void *actions, float *values, float *neglogp, float *states_out,
+                                void *workspace, size_t workspace_bytes, void *stream) {
+    PPO2HIP_REQUIRE(desc && params && obs && actions && values && neglogp && B >= 0, "act_step: bad argument");
+    if (B == 0) return PPO2HIP_OK;
+    const size_t fwd = align_up(ppo2hip_forward_workspace_bytes(desc, B), 256);
+    const size_t need = fwd + align_up((size_t)B * (size_t)desc->ac_dim * sizeof(float), 256);
+    if (!workspace || workspace_bytes < need) {
+        set_error("act_step: workspace too small (%zu < %zu)", workspace_bytes, need);
+        return PPO2HIP_ENOSPACE;
+    }
+    float *pi = (float *)((char *)workspace + fwd);      // the distribution parameters never leave the workspace
+    int rc = ppo2hip_policy_forward(desc, params, obs, B, masks, states_in, pi, values, states_out, workspace, fwd, stream);
+    if (rc) return rc;
+    return ppo2hip_sample_actions(desc, params, pi, B, seed, step, deterministic, actions, neglogp, nullptr, stream);
+}
+
 extern "C" int ppo2hip_ppo_grad(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss, const float *params,
                                 const ppo2hip_rollout *rollout, const int32_t *idx, int64_t B,
                                 const int32_t *mb_envs, int32_t nsteps_mb, const double *stats, float cliprange,

@@ -439,6 +439,9 @@ class PolicySpec:
             out[name] = arena[off:off + n].reshape(shp)
         return out
 
+    def act_workspace_bytes(self, B):
+        return int(lib.ppo2hip_act_workspace_bytes(ctypes.byref(self.desc), B))
+
     def forward_workspace_bytes(self, B):
         return int(lib.ppo2hip_forward_workspace_bytes(ctypes.byref(self.desc), B))
 
@@ -514,6 +517,45 @@ def sample_actions(spec, params, pi, seed, step, deterministic=False, want_noise
                                      int(step) & (2 ** 64 - 1), int(bool(deterministic)), _ptr(actions), _ptr(neglogp),
                                      _ptr(noise), _stream()), "sample_actions")
     return (actions, neglogp, noise) if want_noise else (actions, neglogp)
+
+
+def act_step(spec, params, obs, workspace, seed, step, masks=None, states=None, deterministic=False, actions=None,
+             values=None, neglogp=None):
+    """Forward + sampling + neglogp of one rollout step in one library call.  ``actions`` / ``values`` /
+    ``neglogp`` may be rows of a rollout arena.  Returns (actions, values, new_states or None, neglogp)."""
+    obs = _dev(obs, spec.ob_dtype(), "obs")
+    if tuple(obs.shape[1:]) != tuple(spec.ob_shape()):
+        raise ValueError("obs rows must have shape %s, got %s" % (spec.ob_shape(), tuple(obs.shape[1:])))
+    B = obs.shape[0]
+    dev_ = obs.device
+    if actions is None:
+        actions = (torch.empty((B, spec.ac_dim), dtype=torch.float32, device=dev_) if spec.gaussian
+                   else torch.empty(B, dtype=torch.int32, device=dev_))
+    elif _dev(actions, torch.float32 if spec.gaussian else torch.int32, "actions").numel() != (B * spec.ac_dim if spec.gaussian else B):
+        raise ValueError("actions has the wrong size")
+    if values is None:
+        values = torch.empty((B, spec.nvalue), dtype=torch.float32, device=dev_)
+    elif _dev(values, torch.float32, "values").numel() != B * spec.nvalue:
+        raise ValueError("values has the wrong size")
+    if neglogp is None:
+        neglogp = torch.empty(B, dtype=torch.float32, device=dev_)
+    elif _dev(neglogp, torch.float32, "neglogp").numel() != B:
+        raise ValueError("neglogp has the wrong size")
+    snew = None
+    if spec.recurrent:
+        masks = _dev(_as_u8(masks), torch.uint8, "masks")
+        states = _dev(states, torch.float32, "states")
+        if masks.numel() != B or tuple(states.shape) != (B, 2 * spec.nlstm):
+            raise ValueError("recurrent step needs masks [B] and states [B, 2*nlstm]")
+        snew = torch.empty_like(states)
+    else:
+        masks = states = None
+    wbytes = workspace.numel() * workspace.element_size()
+    check(lib.ppo2hip_act_step(ctypes.byref(spec.desc), _ptr(_dev(params, torch.float32, "params")), _ptr(obs), B, _ptr(masks),
+                               _ptr(states), int(seed) & (2 ** 64 - 1), int(step) & (2 ** 64 - 1), int(bool(deterministic)),
+                               _ptr(actions), _ptr(values), _ptr(neglogp), _ptr(snew), _ptr(workspace), wbytes, _stream()),
+          "act_step")
+    return actions, values, snew, neglogp
 
 
 def done_bootstrap(rewards, dones, v_reset, gamma):

@@ -127,8 +127,7 @@ class _HipPolicy:
     # -- device helpers -------------------------------------------------------------
     def _workspace(self, B):
         if self._ws is None or self._ws_rows < B:
-            self._ws = torch.empty(max(self.spec.forward_workspace_bytes(B), 256), dtype=torch.uint8,
-                                   device=self.device)
+            self._ws = torch.empty(max(self.spec.act_workspace_bytes(B), 256), dtype=torch.uint8, device=self.device)
             self._ws_rows = B
         return self._ws
 
@@ -152,10 +151,9 @@ class _HipPolicy:
         """One act step entirely in HBM: forward, sampling and neglogp.  ``actions`` / ``neglogp`` /
         ``values`` may be rows of a rollout arena to write into.  Returns device (actions, values,
         new_states, neglogp)."""
-        pi, vf, snew = self.forward_dev(ob_dev, mask_dev, state_dev, vf_out=values)
-        a, nlp = hip.sample_actions(self.spec, self.arena.theta, pi, _sample["seed"], _next_sample_step(), deterministic,
-                                    actions=actions, neglogp=neglogp)
-        return a, vf, snew, nlp
+        return hip.act_step(self.spec, self.arena.theta, ob_dev, self._workspace(ob_dev.shape[0]), _sample["seed"],
+                            _next_sample_step(), mask_dev, state_dev, deterministic, actions=actions, values=values,
+                            neglogp=neglogp)
 
     def value_dev(self, ob_dev, state_dev=None, mask_dev=None):
         return self.forward_dev(ob_dev, mask_dev, state_dev)[1]

@@ -284,6 +284,17 @@ int ppo2hip_sample_actions(const ppo2hip_policy_desc *desc, const float *params,
                            uint64_t seed, uint64_t step, int deterministic, void *actions, float *neglogp,
                            float *noise_out, void *stream);
 
+/* One act step of the rollout loop, `model.step(obs, states, dones)` of
+ * baselines/ppo2/common_functions.py:249-251: policy forward, action sampling and neglogp in one
+ * call, each output written where the caller points (a row of the time-major rollout arena).
+ * Arguments as for ppo2hip_policy_forward and ppo2hip_sample_actions; the distribution
+ * parameters stay in the workspace (ppo2hip_act_workspace_bytes(desc, B) bytes). */
+size_t ppo2hip_act_workspace_bytes(const ppo2hip_policy_desc *desc, int64_t B);
+int ppo2hip_act_step(const ppo2hip_policy_desc *desc, const float *params, const void *obs, int64_t B,
+                     const uint8_t *masks, const float *states_in, uint64_t seed, uint64_t step,
+                     int deterministic, void *actions, float *values, float *neglogp, float *states_out,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
 /* The fork's bootstrap of finished envs off the value of the reset observation,
  * baselines/ppo2/common_functions.py:265-276: where dones[e], rewards[e] += gamma * v_reset[e] on
  * every channel if rewards[e][0] > 0, else on channels 2.. only.
