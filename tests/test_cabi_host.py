@@ -226,3 +226,25 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "ppo2hip.h"\nint main(void) { return ppo2hip_version() == 0; }\n')
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], check=True)
+
+
+def test_import_fails_loudly_without_the_library():
+    """No CPU fallback: if libppo2hip.so cannot be loaded, importing the binding raises (fresh process, the
+    loader made to fail for that one file)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes, sys\n"
+            "real = ctypes.CDLL\n"
+            "def cdll(path, *a, **k):\n"
+            "    if str(path).endswith('libppo2hip.so'):\n"
+            "        raise OSError('libppo2hip.so: cannot open shared object file')\n"
+            "    return real(path, *a, **k)\n"
+            "ctypes.CDLL = cdll\n"
+            "try:\n"
+            "    import baselines_amd._lib\n"
+            "except OSError as e:\n"
+            "    print('raised:', e); sys.exit(0)\n"
+            "sys.exit(1)\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "raised:" in r.stdout, r.stdout + r.stderr
