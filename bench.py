@@ -32,6 +32,10 @@ WORKLOADS = {
     # BASELINE.json configs[1]: synthetic MuJoCo-shaped rollout, Gaussian MLP(64,64)
     "mujoco_mlp64": dict(D=17, A=6, E=2048, T=256, hidden=(64, 64), R=1, upstream=True, nmb=4, noptepochs=4,
                          lr=3e-4, cliprange=0.2, ent_coef=0.0, done_p=1.0 / 200),
+    # BASELINE.json configs[3]: one GPU's shard (8192 envs) of the 65536-env x 128-step env-sharded MLP rollout;
+    # run with --gpus 8 for the configuration itself
+    "mlp_env_shard": dict(D=17, A=6, E=8192, T=128, hidden=(64, 64), R=1, upstream=True, nmb=4, noptepochs=4,
+                          lr=3e-4, cliprange=0.2, ent_coef=0.0, done_p=1.0 / 200),
     # the same shape through the fork's own network/loss (256-128, 5 value channels)
     "mujoco_fork": dict(D=17, A=6, E=2048, T=256, hidden=(256, 128), R=5, upstream=False, nmb=4, noptepochs=4,
                         lr=3e-4, cliprange=0.2, ent_coef=0.0, done_p=1.0 / 200),
@@ -366,7 +370,7 @@ def main():
             which = "configs[4]" if cfg.get("nlstm") else "configs[2]"
         else:
             shape = "MuJoCo-shaped rollout: obs_dim=%d act_dim=%d Gaussian MLP%s" % (D, A, str(cfg["hidden"]).replace(" ", ""))
-            which = "configs[1]"
+            which = "configs[3] shard" if args.workload == "mlp_env_shard" else "configs[1]"
         achieved_tf = flops_mb / (grad_ms * 1e-3) / 1e12
         gae_bytes = T * E * (16 * R + 1) + E * (4 * R + 1)
         gae_gbs = gae_bytes / (gae_ms * 1e-3) / 1e9
