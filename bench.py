@@ -207,12 +207,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(args.gpus, 1) and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PPO2HIP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share
+    # devices, gradients staged through the host); the measured configuration is one rank per GPU over RCCL
+    backend = os.environ.get("PPO2HIP_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("rank %d has no GPU of its own (%d visible)" % (local_rank, ndev))
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     comm = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         from baselines_amd.common.mpi_adam import DataParallel
         comm = DataParallel("mpi")
 
@@ -271,7 +281,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     losses = last.cpu().numpy()

@@ -28,3 +28,25 @@ def test_bench_line():
     g = d["gae_roofline"]
     assert g["bound"] == "hbm" and g["unit"] == "GB/s" and 0 < g["frac"] < 1
     assert d["value"] > 1e6 and abs(d["value"] - 524288 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+
+
+def test_bench_two_ranks_rehearsal():
+    """The launch the driver uses for N > 1 (torch.distributed.run, one process per rank), rehearsed with two
+    ranks on this box's one GPU: gloo carries the gradients through the host (PPO2HIP_BENCH_BACKEND=gloo), so
+    the throughput means nothing, but rank handling, barriers, the max-over-ranks clock and the single JSON
+    line from rank 0 are the measured path's."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PPO2HIP_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                          "--warmup", "1"], cwd=ROOT, env=env, check=True, capture_output=True, text=True, timeout=280).stdout
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "dp2" in d["config"]["parallelism"]
+    assert "cpu_baseline" not in d                       # rank 0 at N = 1 only
+    assert abs(d["value"] - 2 * 524288 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
