@@ -5,7 +5,7 @@ resolve, importing this module raises.
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t,
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t,
                     c_uint32, c_uint64, c_void_p)
 
 import torch  # noqa: F401  (loads the process's HIP runtime before ours resolves against it)
