@@ -248,3 +248,24 @@ def test_import_fails_loudly_without_the_library():
             "sys.exit(1)\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "raised:" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address"])
+def test_index_pipeline_under_host_sanitizers(tmp_path, sanitizer):
+    """The worker ring of the index pipeline (token passing between threads, out-of-order epoch completion) built
+    with ThreadSanitizer / AddressSanitizer on the HOST side only and driven through 40 jobs in both modes; the
+    harness also checks every epoch against the one-shot shuffle."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "perm_san")
+    subprocess.run([hipcc, "-O1", "-g", "-std=c++17", "-mavx2", "--offload-arch=gfx950", "-x", "hip", "-Xarch_host",
+                    "-fsanitize=" + sanitizer, "-I", os.path.join(root, "include"), "-o", exe,
+                    os.path.join(root, "tests", "host", "perm_sanitize.cpp"), os.path.join(root, "baselines_amd", "csrc", "perm.cpp"),
+                    "-lpthread"], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "mismatching epochs: 0" in r.stdout, r.stdout + r.stderr
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr
