@@ -269,3 +269,37 @@ def test_index_pipeline_under_host_sanitizers(tmp_path, sanitizer):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "mismatching epochs: 0" in r.stdout, r.stdout + r.stderr
     assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr
+
+
+def test_bad_arguments_are_refused_before_any_launch(lib):
+    """Shape and pointer mistakes come back as PPO2HIP_EINVAL with a message; none of these calls reaches the GPU
+    (they run on a machine without one)."""
+    L = lib.lib
+    null = ctypes.c_void_p(None)
+    one = ctypes.c_void_p(16)            # never dereferenced: the checks below fail first
+    g = (ctypes.c_double * 9)(*([0.99] * 9))
+    calls = {
+        "gae R too large": lambda: L.ppo2hip_gae_f32(one, one, one, one, one, g, 0.95, 4, 4, 9, one, one, one, null),
+        "gae null": lambda: L.ppo2hip_gae_f32(null, one, one, one, one, g, 0.95, 4, 4, 1, one, one, one, null),
+        "discount negative T": lambda: L.ppo2hip_discount(one, 0, null, 0.9, -1, 4, one, 1, null),
+        "discount f64 -> f32": lambda: L.ppo2hip_discount(one, 1, null, 0.9, 4, 4, one, 0, null),
+        "rms empty batch": lambda: L.ppo2hip_rms_update(one, 0, 0, 3, one, one, 4096, null),
+        "moments empty batch": lambda: L.ppo2hip_column_moments(one, 0, 0, 3, one, one, one, 4096, null),
+        "normalize negative clip": lambda: L.ppo2hip_normalize_clip(one, 0, 4, 3, one, one, 1e-8, -1.0, one, 0, null),
+        "frame stack element size": lambda: L.ppo2hip_frame_stack(one, one, null, 2, 10, 1, 4, 2, null),
+        "bootstrap R too large": lambda: L.ppo2hip_done_bootstrap(one, one, one, g, 4, 9, null),
+        "row mean too wide": lambda: L.ppo2hip_row_mean(one, 4, 32, 17, 0.25, one, null),
+        "compose negative n": lambda: L.ppo2hip_compose_i32(one, one, one, -1, null),
+        "compose aliased": lambda: L.ppo2hip_compose_i32(one, one, one, 8, null),
+        "sample null": lambda: L.ppo2hip_sample_actions(None, one, one, 4, 0, 0, 0, one, one, null, null),
+        "act step null": lambda: L.ppo2hip_act_step(None, one, one, 4, null, null, 0, 0, 0, one, one, one, null, one, 1 << 20, null),
+        "add null": lambda: L.ppo2hip_add_f64(null, one, 4, null),
+    }
+    for what, call in calls.items():
+        rc = call()
+        assert rc == lib.EINVAL, (what, rc)
+        assert L.ppo2hip_last_error(), what
+    # empty inputs are fine and launch nothing
+    assert L.ppo2hip_gae_f32(null, null, null, null, null, g, 0.95, 0, 4, 1, null, null, null, null) == 0
+    assert L.ppo2hip_discount(null, 0, null, 0.9, 0, 4, null, 1, null) == 0
+    assert L.ppo2hip_compose_i32(null, null, null, 0, null) == 0
