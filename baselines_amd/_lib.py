@@ -100,6 +100,8 @@ _SIGS = {
                                   _P, c_size_t, _P, _P]),
     "ppo2hip_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_double, c_int64, c_double, c_double, c_double,
                                   c_double, c_double, _P, _P]),
+    "ppo2hip_adam_step_static": (c_int, [_P, _P, _P, _P, c_int64, c_double, c_int64, c_double, c_double, c_double,
+                                         c_double, c_double, _P, _P]),
     "ppo2hip_gemm_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
 }
 

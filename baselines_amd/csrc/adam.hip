@@ -3,6 +3,8 @@
 //   clip : tf.clip_by_global_norm, g * c / max(||g||, c)   (baselines/ppo2/common_functions.py:59-60,
 //          live use baselines/a2c/a2c.py:40-42)
 //   Adam : baselines/common/mpi_adam.py:30-35 with epsilon 1e-5 (common_functions.py:51-52)
+#include <mutex>
+
 #include "kernels.hpp"
 
 namespace ppo2hip {
@@ -92,20 +94,64 @@ __global__ __launch_bounds__(1024) void adam_kernel(float *__restrict__ theta, c
 
 using namespace ppo2hip;
 
+constexpr size_t kScratchBytes = kScratchHeader + kNormBlocks * sizeof(double);
+
+// Scratch of ppo2hip_adam_step_static: the norm header and the per-block partial sums of squares, held by every
+// GPU the library runs on until the process ends.  In host code this name only stands for the symbol; the
+// address the kernels write through is looked up per device in static_scratch().
+static __device__ __align__(256) unsigned char scratch[PPO2HIP_ADAM_STATIC_SCRATCH_BYTES];
+static_assert(kScratchBytes <= PPO2HIP_ADAM_STATIC_SCRATCH_BYTES, "static scratch smaller than the kernels' layout");
+
+constexpr int kMaxDevices = 64;
+static void *g_static_ptr[kMaxDevices];          // device address of `scratch` on each GPU, once looked up
+static std::mutex g_static_mu;
+
+// address of this device's copy of `scratch` (symbol lookup on the first call per device; no allocation)
+static int static_scratch(void **out) {
+    int dev = -1;
+    PPO2HIP_CHECK_HIP(hipGetDevice(&dev));
+    PPO2HIP_REQUIRE(dev >= 0 && dev < kMaxDevices, "adam_step_static: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_static_mu);
+    if (!g_static_ptr[dev]) {
+        void *p = nullptr;
+        PPO2HIP_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        PPO2HIP_REQUIRE(p != nullptr, "adam_step_static: no device address for the scratch symbol");
+        g_static_ptr[dev] = p;
+    }
+    *out = g_static_ptr[dev];
+    return PPO2HIP_OK;
+}
+
 extern "C" size_t ppo2hip_adam_scratch_bytes(int64_t P) {
     (void)P;
-    return kScratchHeader + kNormBlocks * sizeof(double);
+    return kScratchBytes;
+}
+
+extern "C" int ppo2hip_adam_step_static(float *params, const float *grads, float *m, float *v, int64_t P, double lr,
+                                        int64_t t, double beta1, double beta2, double epsilon, double grad_scale,
+                                        double max_grad_norm, float *norm_out, void *stream) {
+    PPO2HIP_REQUIRE(P >= 0 && P <= PPO2HIP_ADAM_STATIC_MAX_PARAMS,
+                    "adam_step_static: P=%lld beyond the supported maximum of %lld parameters", (long long)P,
+                    (long long)PPO2HIP_ADAM_STATIC_MAX_PARAMS);
+    void *sp = nullptr;
+    int rc = static_scratch(&sp);
+    if (rc) return rc;
+    // every call rewrites the header and the partial sums it reads, so nothing of the previous call's contents is used
+    rc = ppo2hip_adam_step(params, grads, m, v, P, lr, t, beta1, beta2, epsilon, grad_scale, max_grad_norm, sp, stream);
+    if (rc || !norm_out || P == 0) return rc;
+    PPO2HIP_CHECK_HIP(hipMemcpyAsync(norm_out, sp, 2 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PPO2HIP_OK;
 }
 
 extern "C" int ppo2hip_adam_step(float *params, const float *grads, float *m, float *v, int64_t P, double lr,
                                  int64_t t, double beta1, double beta2, double epsilon, double grad_scale,
-                                 double max_grad_norm, void *scratch, void *stream) {
+                                 double max_grad_norm, void *ws, void *stream) {
     PPO2HIP_REQUIRE(P >= 0 && t >= 1, "adam_step: bad P=%lld t=%lld", (long long)P, (long long)t);
     if (P == 0) return PPO2HIP_OK;
-    PPO2HIP_REQUIRE(params && grads && m && v && scratch, "adam_step: null pointer");
+    PPO2HIP_REQUIRE(params && grads && m && v && ws, "adam_step: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    float *header = (float *)scratch;
-    double *partial = (double *)((char *)scratch + kScratchHeader);
+    float *header = (float *)ws;
+    double *partial = (double *)((char *)ws + kScratchHeader);
     int npartial = 0;
     if (max_grad_norm > 0.0 && P > 65536) {
         npartial = (int)(ceil_div(P, 1024) < kNormBlocks ? ceil_div(P, 1024) : kNormBlocks);

@@ -333,6 +333,22 @@ int ppo2hip_adam_step(float *params, const float *grads, float *m, float *v, int
                       int64_t t, double beta1, double beta2, double epsilon, double grad_scale,
                       double max_grad_norm, void *scratch, void *stream);
 
+/* ppo2hip_adam_step for callers that cannot allocate or pass device scratch (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  The norm header and partial sums live in a PPO2HIP_ADAM_STATIC_SCRATCH_BYTES-byte array
+ * that is part of the library's device image (every GPU the library runs on holds one until the process
+ * ends); the call allocates and frees nothing.  Arguments and arithmetic are those of ppo2hip_adam_step.
+ *   P        : at most PPO2HIP_ADAM_STATIC_MAX_PARAMS, else PPO2HIP_EINVAL
+ *   norm_out : device float[2] or NULL — {global gradient norm (written when clipping), applied scale}
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (different
+ * streams or threads) race; calls on one stream, or otherwise ordered, are safe.  Every call rewrites
+ * what it later reads, so the previous call's contents never matter. */
+#define PPO2HIP_ADAM_STATIC_SCRATCH_BYTES 2304
+#define PPO2HIP_ADAM_STATIC_MAX_PARAMS (1ll << 26)
+int ppo2hip_adam_step_static(float *params, const float *grads, float *m, float *v, int64_t P, double lr,
+                             int64_t t, double beta1, double beta2, double epsilon, double grad_scale,
+                             double max_grad_norm, float *norm_out, void *stream);
+
 /* One epoch's minibatch loop (baselines/ppo2/ppo2.py:114-118) of a feed-forward policy in one
  * call, single process: for j < N / nbatch_train, ppo2hip_ppo_grad on idx[j*nbatch_train ..),
  * normalised with stats[j] ({sum, sumsq, count} rows of ppo2hip_adv_stats, or NULL), losses to
