@@ -2,7 +2,8 @@
 // write of (theta, m, v) — 28 B per parameter, plus a 4 B/param norm pass when clipping.
 //   clip : tf.clip_by_global_norm, g * c / max(||g||, c)   (baselines/ppo2/common_functions.py:59-60,
 //          live use baselines/a2c/a2c.py:40-42)
-//   Adam : baselines/common/mpi_adam.py:30-35 with epsilon 1e-5 (common_functions.py:51-52)
+//   Adam : baselines/common/mpi_adam.py:30-35 with epsilon 1e-5 (common_functions.py:51-52).  As there, 1 - beta is
+//          formed in double and then rounded to float32 (1.f - 0.999f would be off by 4.7e-5 relative)
 #include <mutex>
 
 #include "kernels.hpp"
@@ -27,7 +28,7 @@ __global__ void sumsq_partial_kernel(const float *__restrict__ g, int64_t P, flo
 // WHOLE gradient itself (same order in every block, hence the same norm) and no separate
 // norm launch is needed.  Loads are issued in batches so that a batch costs one round trip.
 __global__ __launch_bounds__(1024) void adam_kernel(float *__restrict__ theta, const float *__restrict__ g, float *__restrict__ m,
-                            float *__restrict__ v, int64_t P, float a, float beta1, float beta2, float eps,
+                            float *__restrict__ v, int64_t P, float a, float beta1, float beta2, float omb1, float omb2, float eps,
                             float gscale, float max_norm, const double *__restrict__ partial, int npartial,
                             float *__restrict__ header) {
     __shared__ float scale_s;
@@ -75,7 +76,6 @@ __global__ __launch_bounds__(1024) void adam_kernel(float *__restrict__ theta, c
     }
     __syncthreads();
     const float scale = scale_s;
-    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int64_t i = first + (int64_t)u * nt + tid;
@@ -165,7 +165,7 @@ extern "C" int ppo2hip_adam_step(float *params, const float *grads, float *m, fl
     const int64_t nb = ceil_div(P, (int64_t)threads * 4);      // 4 elements per thread
     PPO2HIP_REQUIRE(nb <= 0x7fffffffll, "adam_step: arena too large");
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(threads), 0, s, params, grads, m, v, P, (float)a,
-                       (float)beta1, (float)beta2, (float)epsilon, (float)grad_scale, (float)max_grad_norm, partial,
+                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)epsilon, (float)grad_scale, (float)max_grad_norm, partial,
                        npartial, header);
     return check_launch("adam_kernel");
 }

@@ -75,6 +75,8 @@ class Model(object):
         self._losses = torch.zeros((1, 8), dtype=torch.float32, device=self.device)
         if comm is not None:
             comm.bcast_(self.arena.theta)          # MpiAdam.sync, baselines/common/mpi_adam.py:37-40
+            from . import policies as _policies
+            _policies.set_sample_rank(comm.rank)   # every rank samples its own action noise
 
         self.loss_names = ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
         self.train_model = train_model

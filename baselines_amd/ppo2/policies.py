@@ -8,6 +8,7 @@ registry keyed by scope name: ``reuse=True`` shares the arena created by the
 ``reuse=False`` call of the same scope, as ``tf.variable_scope(..., reuse=reuse)`` does.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -17,14 +18,29 @@ from ..a2c.utils import ortho_init
 from ..common.distributions import make_pdtype
 
 _SCOPES = {}
-_sample = {"seed": 0, "step": 0}
+_sample = {"seed": None, "step": 0, "rank": 0}
+_RANK_STRIDE = 0x9E3779B97F4A7C15      # odd 64-bit constant: ranks get well separated Philox keys
 
 
 def set_sample_seed(seed):
     """Seed of the action-sampling noise (the reference samples with TensorFlow's own RNG,
     baselines/common/distributions.py:164-166,211-212, which no other RNG reproduces).  The noise of
-    a step is a function of (seed, number of sampling calls since the seed was set, env row)."""
+    a step is a function of (seed, number of sampling calls since the seed was set, env row).  Without
+    this call the seed is drawn from the OS on first use, as TensorFlow's unseeded graph draws its own
+    per process."""
     _sample["seed"], _sample["step"] = int(seed), 0
+
+
+def set_sample_rank(rank):
+    """Data-parallel runs: rank r keys its noise with seed + r * (odd constant), so that env row i of two
+    ranks does not draw the same noise (the reference's processes sample independently)."""
+    _sample["rank"] = int(rank)
+
+
+def _sample_seed():
+    if _sample["seed"] is None:
+        _sample["seed"] = int.from_bytes(os.urandom(8), "little")
+    return (_sample["seed"] + _sample["rank"] * _RANK_STRIDE) & (2 ** 64 - 1)
 
 
 def _next_sample_step():
@@ -48,15 +64,17 @@ class _Placeholder:
 class ParamArena:
     """Flat parameter vector of one variable scope (device float32) + its layout."""
 
-    def __init__(self, spec, device):
+    def __init__(self, spec, device, pi_scale=0.01):
         self.spec = spec
         self.theta = torch.zeros(spec.nparams, dtype=torch.float32, device=device)
-        self.init_from_numpy_rng()
+        self.init_from_numpy_rng(pi_scale)
 
     def init_from_numpy_rng(self, pi_scale=0.01):
         """Initial values in variable creation order, each weight drawing its normals from the
         global np.random stream as ortho_init does (baselines/a2c/utils.py:35): sqrt(2) trunks,
-        0.01 policy head, 1.0 value head / LSTM matrices, zero biases and logstd, unit LN gains."""
+        ``pi_scale`` policy head (0.01 where the reference passes ``init_scale=0.01``, fc's default 1.0
+        for the recurrent policies, baselines/ppo2/policies.py:33,75), 1.0 value head / LSTM matrices,
+        zero biases and logstd, unit LN gains."""
         host = np.zeros(self.spec.nparams, np.float32)
         for name, off, shp in self.spec.vars:
             leaf = name.split("/")[-1]
@@ -95,7 +113,7 @@ class ParamArena:
         self.set_list([d[name] for name, _, _ in self.spec.vars])
 
 
-def _get_arena(scope, reuse, spec, device):
+def _get_arena(scope, reuse, spec, device, pi_scale=0.01):
     if reuse:
         if scope not in _SCOPES:
             raise ValueError("variable scope %r does not exist (reuse=True)" % scope)
@@ -103,7 +121,7 @@ def _get_arena(scope, reuse, spec, device):
         if arena.spec.nparams != spec.nparams:
             raise ValueError("scope %r holds a different network" % scope)
         return arena
-    arena = ParamArena(spec, device)
+    arena = ParamArena(spec, device, pi_scale)
     _SCOPES[scope] = arena
     return arena
 
@@ -112,12 +130,14 @@ class _HipPolicy:
     """Shared behaviour: forward, action sampling and neglogp in HIP; the host methods only move arrays."""
 
     recurrent = False
+    pi_init_scale = 0.01     # fc(.., 'pi', .., init_scale=0.01): baselines/ppo2/policies.py:109,143, a2c/policies.py pdfromlatent
 
     def _setup(self, spec, scope, reuse, ob_space, ac_space, nbatch):
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.spec = spec
-        self.arena = _get_arena(scope, reuse, spec, self.device)
+        self.arena = _get_arena(scope, reuse, spec, self.device, self.pi_init_scale)
         self.pdtype = make_pdtype(ac_space)
+        self.pd = _PdHandle(self)
         self.X = _Placeholder(ob_space.dtype if spec.kind != _lib.POLICY_MLP else np.float32,
                               (nbatch,) + tuple(ob_space.shape))
         self.initial_state = None
@@ -151,7 +171,7 @@ class _HipPolicy:
         """One act step entirely in HBM: forward, sampling and neglogp.  ``actions`` / ``neglogp`` /
         ``values`` may be rows of a rollout arena to write into.  Returns device (actions, values,
         new_states, neglogp)."""
-        return hip.act_step(self.spec, self.arena.theta, ob_dev, self._workspace(ob_dev.shape[0]), _sample["seed"],
+        return hip.act_step(self.spec, self.arena.theta, ob_dev, self._workspace(ob_dev.shape[0]), _sample_seed(),
                             _next_sample_step(), mask_dev, state_dev, deterministic, actions=actions, values=values,
                             neglogp=neglogp)
 
@@ -171,6 +191,27 @@ class _HipPolicy:
     def _squeeze_v(self, v):
         return v
 
+    # -- the reference's graph attributes ---------------------------------------------
+    # ``pi`` / ``vf`` are tensors in the reference (baselines/ppo2/policies.py:53-54,95-96,127-128,175-177), read
+    # by callers through ``sess.run(policy.pi, {policy.X: ob})``; with no graph here they are the same
+    # quantities as functions of the observation batch (recurrent policies: also state and mask).
+    def pi(self, ob, state=None, mask=None):
+        """Distribution parameters of ``ob``: Gaussian mean or Categorical logits, [B, ac_dim]."""
+        return self._forward_host(ob, state, mask)[0]
+
+    def vf(self, ob, state=None, mask=None):
+        """Value head of ``ob`` as the reference's ``vf`` tensor holds it ([B, R], or [B] where it is ``[:, 0]``)."""
+        return self._squeeze_v(self._forward_host(ob, state, mask)[1])
+
+    def _forward_host(self, ob, state=None, mask=None):
+        ob_dev = self._to_dev_obs(ob)
+        m_dev = s_dev = None
+        if self.recurrent:
+            s_dev = torch.from_numpy(np.ascontiguousarray(state, np.float32)).to(self.device)
+            m_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(mask).astype(np.uint8))).to(self.device)
+        pi, vf, _ = self.forward_dev(ob_dev, m_dev, s_dev)
+        return pi.cpu().numpy(), vf.cpu().numpy()
+
     # -- the reference's callables ----------------------------------------------------
     def step(self, ob, *args, **_kwargs):
         state = args[0] if len(args) > 0 else None
@@ -185,6 +226,33 @@ class _HipPolicy:
             m_dev = torch.from_numpy(np.ascontiguousarray(np.asarray(args[1]).astype(np.uint8))).to(self.device)
         _, vf, _ = self.forward_dev(ob_dev, m_dev, s_dev)
         return self._squeeze_v(vf.cpu().numpy())
+
+
+class _PdHandle:
+    """``policy.pd`` (``pdtype.pdfromflat(..)``, baselines/ppo2/policies.py:37,79,113,154): the action
+    distribution as functions of an observation batch — ``mode``, ``neglogp``, ``sample`` evaluated by the
+    kernels of baselines_amd/csrc/loss.hip and sample.hip, and ``std`` for the Gaussian."""
+
+    def __init__(self, policy):
+        self._p = policy
+
+    def mode(self, ob, state=None, mask=None):
+        p = self._p
+        pi = p.pi(ob, state, mask)
+        return pi if p.spec.gaussian else pi.argmax(axis=1)
+
+    def neglogp(self, ob, actions, state=None, mask=None):
+        p = self._p
+        pi = torch.from_numpy(np.ascontiguousarray(p.pi(ob, state, mask))).to(p.device)
+        a = torch.from_numpy(np.ascontiguousarray(actions, np.float32 if p.spec.gaussian else np.int32)).to(p.device)
+        return hip.neglogp(p.spec, p.arena.theta, pi, a).cpu().numpy()
+
+    def sample(self, ob, state=None, mask=None):
+        return self._p._act(ob, state, mask, False)[0]
+
+    @property
+    def std(self):
+        return np.exp(self._p.logstd_host())
 
 
 class MlpPolicy(_HipPolicy):
@@ -258,6 +326,7 @@ class LstmPolicy(_HipPolicy):
     signature = "upstream"
     kind = _lib.POLICY_CNN_LSTM
     recurrent = True
+    pi_init_scale = 1.0      # fc(h5, 'pi', nact) with fc's default init_scale (baselines/ppo2/policies.py:33,75)
 
     def __init__(self, sess, ob_space, ac_space, nbatch, nsteps, nlstm=256, reuse=False):  # pylint: disable=W0613
         nenv = nbatch // nsteps

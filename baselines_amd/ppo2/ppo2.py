@@ -18,10 +18,41 @@ from .common_functions import *   # noqa: F401,F403  (Model, Runner, sf01, const
 from .common_functions import Model, Runner, compute_advs, constfn
 
 
+def num_updates(total_timesteps, nbatch):
+    """``nupdates = total_timesteps//nbatch`` (baselines/ppo2/ppo2.py:69)."""
+    return int(total_timesteps) // nbatch
+
+
+def update_schedule(update, nupdates, lr, cliprange, upstream=False):
+    """(frac, lrnow, cliprangenow) of update number ``update`` (1-based), baselines/ppo2/ppo2.py:78-83:
+    ``frac = 1 - (update-1)/nupdates``; the fork multiplies the schedule's value by ``frac`` once more
+    (``lrnow = frac*lr(frac)``, :79) and floors the two at 1e-4 and 0.1 (``np.clip(.., 1e-4, 1)``, :82;
+    ``np.clip(.., 0.1, 1)``, :83).  ``upstream``: the schedule's own values, unclipped."""
+    frac = 1.0 - (update - 1.0) / nupdates
+    if upstream:
+        return frac, lr(frac), cliprange(frac)
+    return frac, np.clip(frac * lr(frac), 1e-4, 1), np.clip(cliprange(frac), 0.1, 1)
+
+
+def update_fps(nbatch, seconds):
+    """``fps = int(nbatch / (tnow - tstart))`` (baselines/ppo2/ppo2.py:141)."""
+    return int(nbatch / seconds)
+
+
+REFERENCE_CHECKPOINT_DIR = osp.join('../model', 'checkpoints')   # baselines/ppo2/ppo2.py:178
+
+
 def learn(*, policy, env, nsteps, total_timesteps, ent_coef, lr,
           vf_coef=0.5, max_grad_norm=0.5, gamma=0.99, lam=0.95,
           log_interval=10, nminibatches=4, noptepochs=4, cliprange=0.2,
-          save_interval=0, upstream=None, comm=None, device_path=True, return_model=False):
+          save_interval=0, upstream=None, comm=None, device_path=True, return_model=False,
+          checkpoint_dir=None, reference_rng_parity=False):
+    """Build-only keyword arguments beyond the reference's: ``upstream``, ``comm`` (a DataParallel context),
+    ``device_path`` (False = the reference's host minibatch loop through ``Model.train``), ``return_model``,
+    ``checkpoint_dir`` (None = the reference's literal ``../model/checkpoints``, :178), and
+    ``reference_rng_parity``: the fork also builds the never-used ``model_pf`` and ``model_pf_2`` (:45-46),
+    whose ``ortho_init`` draws advance the global ``np.random`` stream before the first shuffle; True
+    consumes the same draws so that a seeded run's index stream lines up with the fork's end to end."""
     if isinstance(lr, float): lr = constfn(lr)
     else: assert callable(lr)
     if isinstance(cliprange, float): cliprange = constfn(cliprange)
@@ -41,27 +72,22 @@ def learn(*, policy, env, nsteps, total_timesteps, ent_coef, lr,
         nbatch_train=nbatch_train, nsteps=nsteps, ent_coef=ent_coef, vf_coef=vf_coef, lr=lr(1),
         max_grad_norm=max_grad_norm, need_summary=need_summary, upstream_loss=upstream, comm=comm)
     model = make_model('model', need_summary=True)
-    # The fork also builds 'model_pf' and 'model_pf_2' (:45-46); they are never used by the live
-    # code and are not built here.
+    # The fork also builds 'model_pf' and 'model_pf_2' (:45-46); the live code never uses them.  They are not
+    # kept here; with reference_rng_parity their initialisers' draws are consumed from np.random all the same.
+    if reference_rng_parity:
+        for extra in ('model_pf', 'model_pf_2'):
+            make_model(extra, need_summary=False)
 
     runner = Runner(env=env, model=model, nsteps=nsteps, gamma=gamma, lam=lam)
     epinfobuf = deque(maxlen=100)
     tfirststart = time.time()
-    nupdates = total_timesteps // nbatch
+    nupdates = num_updates(total_timesteps, nbatch)
     max_return = [200, 120, 0, 0, 0]   # :71
 
     for update in range(1, nupdates + 1):
-        if upstream:
-            assert nbatch % nminibatches == 0
-        else:
-            assert nbatch % nminibatches == 0   # :74
+        assert nbatch % nminibatches == 0   # :74
         tstart = time.time()
-        frac = 1.0 - (update - 1.0) / nupdates
-        lrnow = frac * lr(frac) if not upstream else lr(frac)     # fork: frac*lr(frac) (:79)
-        cliprangenow = cliprange(frac)
-        if not upstream:
-            lrnow = np.clip(lrnow, 1e-4, 1)                       # :82
-            cliprangenow = np.clip(cliprangenow, 0.1, 1)          # :83
+        frac, lrnow, cliprangenow = update_schedule(update, nupdates, lr, cliprange, upstream)   # :78-83
         obs, returns, masks, actions, values, rewards, neglogpacs, states, epinfos, ret = runner.run(is_test=False)
         epinfobuf.extend(epinfos)
         ro = runner.rollout
@@ -107,7 +133,7 @@ def learn(*, policy, env, nsteps, total_timesteps, ent_coef, lr,
                         mblossvals.append(model.train(float(lrnow), float(cliprangenow), *slices, states[mbenvinds]))
             lossvals = np.mean(mblossvals, axis=0)
         tnow = time.time()
-        fps = int(nbatch / (tnow - tstart))
+        fps = update_fps(nbatch, tnow - tstart)
         if update % log_interval == 0 or update == 1:
             logger.logkv("serial_timesteps", update * nsteps)
             logger.logkv("nupdates", update)
@@ -121,7 +147,7 @@ def learn(*, policy, env, nsteps, total_timesteps, ent_coef, lr,
                 logger.logkv(lossname, float(lossval))
             logger.dumpkvs()
         if save_interval and (update % save_interval == 0 or update == 1 or update == nupdates) and logger.get_dir():
-            checkdir = osp.join(logger.get_dir(), 'checkpoints')
+            checkdir = REFERENCE_CHECKPOINT_DIR if checkpoint_dir is None else checkpoint_dir
             os.makedirs(checkdir, exist_ok=True)
             model.save(osp.join(checkdir, '%.5i' % update), osp.join(checkdir, '%.5i' % 0))
     env.close()
