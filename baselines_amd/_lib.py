@@ -92,6 +92,8 @@ _SIGS = {
     "ppo2hip_policy_forward": (c_int, [POINTER(PolicyDesc), _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "ppo2hip_neglogp": (c_int, [POINTER(PolicyDesc), _P, _P, _P, c_int64, _P, _P]),
     "ppo2hip_grad_workspace_bytes": (c_size_t, [POINTER(PolicyDesc), c_int64]),
+    "ppo2hip_grad_workspace_region": (c_int, [POINTER(PolicyDesc), c_int64, c_int32, c_char_p, POINTER(c_size_t),
+                                              POINTER(c_int64)]),
     "ppo2hip_ppo_grad": (c_int, [POINTER(PolicyDesc), POINTER(LossDesc), _P, POINTER(Rollout), _P, c_int64, _P,
                                  c_int32, _P, c_float, c_double, _P, _P, _P, c_size_t, _P]),
     "ppo2hip_adam_scratch_bytes": (c_size_t, [c_int64]),

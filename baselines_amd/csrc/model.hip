@@ -603,6 +603,35 @@ extern "C" size_t ppo2hip_grad_workspace_bytes(const ppo2hip_policy_desc *desc, 
     return 0;
 }
 
+extern "C" int ppo2hip_grad_workspace_region(const ppo2hip_policy_desc *desc, int64_t B, int32_t nsteps_mb, const char *name,
+                                             size_t *offset_bytes, int64_t *nelems) {
+    PPO2HIP_REQUIRE(desc && name && offset_bytes && nelems && B >= 1, "grad_workspace_region: bad argument");
+    PPO2HIP_REQUIRE(cnn_kind(*desc), "grad_workspace_region: nature_cnn policies only");
+    Layout L;
+    int rc = build_layout(*desc, L);
+    if (rc) return rc;
+    const CnnDims k = cnn_dims(*desc);
+    int nenv = 1;
+    if (k.lstm) {
+        PPO2HIP_REQUIRE(nsteps_mb >= 1 && B % nsteps_mb == 0, "grad_workspace_region: nsteps_mb must divide B");
+        nenv = (int)(B / nsteps_mb);
+    }
+    char *const base = (char *)4096;           // never dereferenced: only the carve-outs' distances from it are used
+    Carver c(base, (size_t)1 << 62);
+    CnnBuf w{};
+    carve_cnn(*desc, B, nenv, c, w, true);
+    const float *ptr = nullptr;
+    int64_t n = 0;
+    if (!std::strcmp(name, "c1")) { ptr = w.Y1; n = B * k.h1 * k.w1 * 32; }
+    else if (!std::strcmp(name, "c2")) { ptr = w.Y2; n = B * k.h2 * k.w2 * 64; }
+    else if (!std::strcmp(name, "c3")) { ptr = w.Y3; n = B * k.flat; }
+    else if (!std::strcmp(name, "fc1")) { ptr = w.F; n = B * 512; }
+    else { set_error("grad_workspace_region: unknown region '%s'", name); return PPO2HIP_EINVAL; }
+    *offset_bytes = (size_t)((const char *)ptr - base);
+    *nelems = n;
+    return PPO2HIP_OK;
+}
+
 extern "C" int ppo2hip_policy_forward(const ppo2hip_policy_desc *desc, const float *params, const void *obs,
                                       int64_t B, const uint8_t *masks, const float *states_in, float *pi,
                                       float *vf, float *states_out, void *workspace, size_t workspace_bytes,

@@ -637,6 +637,17 @@ def ppo_grad(spec, loss_desc, params, rollout, idx, B, stats, cliprange, inv_cou
           "ppo_grad")
 
 
+def grad_workspace_region(spec, workspace, B, name, nsteps_mb=0):
+    """View of one of the nature_cnn trunk's activation blocks ("c1", "c2", "c3", "fc1") inside a gradient
+    workspace, as the last ``ppo_grad`` call with this (B, nsteps_mb) left it (for tests)."""
+    off, n = ctypes.c_size_t(0), ctypes.c_int64(0)
+    check(lib.ppo2hip_grad_workspace_region(ctypes.byref(spec.desc), int(B), int(nsteps_mb), name.encode(), ctypes.byref(off),
+                                            ctypes.byref(n)), "grad_workspace_region")
+    if off.value + 4 * n.value > workspace.numel() * workspace.element_size():
+        raise ValueError("workspace smaller than the region")
+    return workspace.view(torch.uint8)[off.value:off.value + 4 * n.value].view(torch.float32)
+
+
 def adam_scratch(P, device):
     return torch.zeros(int(lib.ppo2hip_adam_scratch_bytes(P)), dtype=torch.uint8, device=device)
 

@@ -270,6 +270,14 @@ int ppo2hip_neglogp(const ppo2hip_policy_desc *desc, const float *params, const 
                     const void *actions, int64_t B, float *neglogp, void *stream);
 
 size_t ppo2hip_grad_workspace_bytes(const ppo2hip_policy_desc *desc, int64_t B);
+/* Exposed for tests: where ppo2hip_ppo_grad leaves the rectified activations of the nature_cnn trunk
+ * (baselines/ppo2/policies.py:12-16) in its workspace after a call with the same (desc, B, nsteps_mb).
+ *   name : "c1" [B,OH1,OW1,32], "c2" [B,OH2,OW2,64], "c3" [B, flat] (NHWC flatten), "fc1" [B,512]; float32
+ *   offset_bytes, nelems : HOST out.  A parity test reads the on/off pattern of the rectifiers from them:
+ *   a float64 restatement disagrees with any float32 evaluation on the few units within rounding of zero. */
+int ppo2hip_grad_workspace_region(const ppo2hip_policy_desc *desc, int64_t B, int32_t nsteps_mb, const char *name,
+                                  size_t *offset_bytes, int64_t *nelems);
+
 /* Action sampling with its neglogp: `a0 = pd.sample(); neglogp0 = pd.neglogp(a0)` of the act graph,
  * baselines/ppo2/policies.py:168-170 (fork) and baselines/a2c/policies.py:137-139; Gaussian
  * `mean + std * N(0,1)` (baselines/common/distributions.py:211-212), Categorical Gumbel-max

@@ -133,21 +133,34 @@ def conv(x_nhwc, p, scope, stride):
     return y.permute(0, 2, 3, 1)
 
 
-def nature_cnn(p, obs_u8):
+def nature_cnn(p, obs_u8, relu_on=None, acts_out=None):
     """``baselines/ppo2/policies.py:6-16``; flatten keeps NHWC order (``conv_to_fc``
-    ``baselines/a2c/utils.py:149-152``)."""
+    ``baselines/a2c/utils.py:149-152``).
+
+    ``relu_on``: optional four boolean arrays (c1, c2, c3 outputs in NHWC, fc1 output) that say which units
+    are switched on; the rectifiers then multiply by them instead of testing their own input's sign.  A float32
+    implementation and this float64 one disagree about the sign of the few pre-activations that lie within
+    float32 rounding of zero (a handful among 10^7), and each such unit opens or closes a whole gradient
+    path; with the implementation's own on/off pattern handed in, the two compute the same function.
+    ``acts_out``: optional list that receives the four activations."""
     dtype = p["c1/w"].dtype
     x = obs_u8.to(dtype) / 255.0
-    h = F.relu(conv(x, p, "c1", 4))
-    h = F.relu(conv(h, p, "c2", 2))
-    h = F.relu(conv(h, p, "c3", 1))
+
+    def rect(z, i):
+        h = F.relu(z) if relu_on is None else z * torch.as_tensor(relu_on[i]).reshape(z.shape).to(dtype)
+        if acts_out is not None:
+            acts_out.append(h)
+        return h
+    h = rect(conv(x, p, "c1", 4), 0)
+    h = rect(conv(h, p, "c2", 2), 1)
+    h = rect(conv(h, p, "c3", 1), 2)
     h = h.reshape(h.shape[0], -1)
-    return F.relu(fc(h, p, "fc1"))
+    return rect(fc(h, p, "fc1"), 3)
 
 
-def cnn_forward(p, obs_u8):
+def cnn_forward(p, obs_u8, relu_on=None, acts_out=None):
     """``CnnPolicy``, ``baselines/ppo2/policies.py:100-130``; returns (logits, vf[B,1])."""
-    h = nature_cnn(p, obs_u8)
+    h = nature_cnn(p, obs_u8, relu_on, acts_out)
     return fc(h, p, "pi"), fc(h, p, "v")
 
 
@@ -192,9 +205,9 @@ def lstm_forward(p, xs, masks, state, nenv, nsteps, layer_norm=False):
     return hs, torch.cat([c, h], dim=1)
 
 
-def cnn_lstm_forward(p, obs_u8, masks, state, nenv, nsteps, layer_norm=False):
+def cnn_lstm_forward(p, obs_u8, masks, state, nenv, nsteps, layer_norm=False, relu_on=None, acts_out=None):
     """``LstmPolicy`` / ``LnLstmPolicy``, ``baselines/ppo2/policies.py:18-98``."""
-    h = nature_cnn(p, obs_u8)
+    h = nature_cnn(p, obs_u8, relu_on, acts_out)
     h5, snew = lstm_forward(p, h, masks, state, nenv, nsteps, layer_norm)
     return fc(h5, p, "pi"), fc(h5, p, "v"), snew
 
@@ -338,20 +351,21 @@ class TrainOracle:
         self.last_grads = None
         self.last_grad_norm = None
 
-    def forward(self, obs, masks=None, states=None):
+    def forward(self, obs, masks=None, states=None, relu_on=None):
         p = self.p
+        self.last_acts = []     # the rectified activations of the nature_cnn trunk (c1, c2, c3, fc1), when there is one
         if self.kind == "mlp":
             pi, vf = mlp_forward(p, torch.as_tensor(obs).to(self.dtype))
             snew = None
         elif self.kind == "cnn":
-            pi, vf = cnn_forward(p, torch.as_tensor(obs))
+            pi, vf = cnn_forward(p, torch.as_tensor(obs), relu_on, self.last_acts)
             snew = None
         else:
             nenv = states.shape[0]
             pi, vf, snew = cnn_lstm_forward(
                 p, torch.as_tensor(obs), torch.as_tensor(masks).to(self.dtype),
                 torch.as_tensor(states).to(self.dtype), nenv, obs.shape[0] // nenv,
-                layer_norm=(self.kind == "lnlstm"))
+                layer_norm=(self.kind == "lnlstm"), relu_on=relu_on, acts_out=self.last_acts)
         return pi, vf, snew
 
     def neglogp_entropy(self, pi, actions):
@@ -361,7 +375,9 @@ class TrainOracle:
         return categorical_neglogp(pi, torch.as_tensor(actions)), categorical_entropy(pi)
 
     def train(self, lr, cliprange, obs, returns, masks, actions, values, advs, neglogpacs,
-              states=None, normalize=True, apply=True):
+              states=None, normalize=True, apply=True, relu_on=None):
+        """``relu_on``: see :func:`nature_cnn` — the on/off pattern of the rectifiers, taken from the implementation
+        under test, so that units within float32 rounding of zero take the same side in both."""
         advs = np.asarray(advs)
         if normalize:
             advs = (advs - advs.mean()) / (advs.std() + 1e-8)
@@ -375,7 +391,7 @@ class TrainOracle:
         }
         for t in self.p.values():
             t.grad = None
-        pi, vf, _ = self.forward(obs, masks, states)
+        pi, vf, _ = self.forward(obs, masks, states, relu_on)
         nlp, ent = self.neglogp_entropy(pi, actions)
         total, scalars = ppo_losses(nlp, ent, vf, batch, cliprange, self.cfg)
         plist = list(self.p.values())

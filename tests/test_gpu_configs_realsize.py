@@ -9,6 +9,9 @@
   * nature_cnn + LSTM(256), env-sequence minibatches with the full 128-step depth and done-mask resets at
     p = 1/20: 16 envs x 128 steps against the oracle, 128 envs x 128 steps against the sum over 8 env chunks.
 
+The nature_cnn comparisons hand the implementation's own rectifier on/off pattern to the restatement (see
+_rectifier_pattern) and check the rectified activations themselves to 2e-5.
+
 Tolerances: losses rtol 5e-5; gradients 5e-5 of the per-variable max; post-update parameters atol 5e-6."""
 import numpy as np
 import pytest
@@ -114,6 +117,22 @@ def _device_image_rollout(hip, spec, theta, T, E, hwc, nact, seed, done_p, nlstm
     return dict(obs=obs, dones=dones, actions=actions, values=values, nlp=nlp, returns=returns, advs=advs, states=states0)
 
 
+def _rectifier_pattern(hip, spec, ws, B, nsteps_mb=0):
+    """The rectified activations ppo_grad left in its workspace -> (on/off pattern per layer, the activations).  The
+    float64 restatement is then evaluated with the same units switched on: among ~10^7 pre-activations a handful lie
+    within float32 rounding of zero, the two sides take different signs there, and every such unit opens or closes a
+    whole gradient path (1e-2 of a bias gradient at these sizes) without either side being wrong."""
+    acts = [hip.grad_workspace_region(spec, ws, B, name, nsteps_mb).cpu().numpy() for name in ("c1", "c2", "c3", "fc1")]
+    return [a > 0 for a in acts], acts
+
+
+def _check_activations(oracle, acts):
+    for name, mine, theirs in zip(("c1", "c2", "c3", "fc1"), acts, oracle.last_acts):
+        t = theirs.detach().numpy().reshape(-1)
+        err = float(np.abs(mine - t).max())
+        assert err <= 2e-5, (name, err)
+
+
 def _host_rows(ro, idx_dev, T, E):
     """The minibatch rows the env-major flat indices name, on the host (what ``arr[mbinds]`` hands to Model.train)."""
     s = idx_dev.long()
@@ -142,6 +161,7 @@ def test_nature_cnn_minibatch_of_8192(mods):
     hip.ppo_grad(spec, loss_desc, theta, rref, idx, B, stats, 0.1, 1.0 / B, grads, losses, ws)
     full_g, full_l = grads.cpu().numpy().astype(np.float64), losses.cpu().numpy()[:5].astype(np.float64)
     assert np.all(np.isfinite(full_g))
+    relu_on, acts = _rectifier_pattern(hip, spec, ws, B)
     # the same minibatch as 8 chunks of 1024 rows, each scaled by 1/8192 and normalised with the whole minibatch's statistics
     sum_g, sum_l = np.zeros_like(full_g), np.zeros(5)
     cb = B // nchunk
@@ -155,7 +175,8 @@ def test_nature_cnn_minibatch_of_8192(mods):
     rows = _host_rows(ro, idx, T, E)
     oracle = tfgraph.TrainOracle(params, "cnn", "categorical", tfgraph.LossCfg(0.01, 0.5, 0.5, True))
     o_losses = oracle.train(2.5e-4, 0.1, rows["obs"], rows["ret"], None, rows["act"], rows["val"],
-                            _normalised(rows["adv"], stats.cpu().numpy()[0]), rows["nlp"], normalize=False)
+                            _normalised(rows["adv"], stats.cpu().numpy()[0]), rows["nlp"], normalize=False, relu_on=relu_on)
+    _check_activations(oracle, acts)
     np.testing.assert_allclose(full_l, o_losses, rtol=5e-5, atol=1e-7)
     want = np.concatenate([oracle.last_grads[name].numpy().ravel() for name, _, _ in spec.vars])
     _check_grads(spec, full_g, want, "8192 rows vs oracle")
@@ -199,12 +220,14 @@ def test_cnn_lstm_full_depth_env_sequences(mods):
     stats = hip.adv_stats(ro["advs"], flat, B, 1, T, E)
     hip.ppo_grad(spec, loss_desc, theta, rref, flat, B, stats, 0.1, 1.0 / B, grads, losses, ws, mb_envs=envs, nsteps_mb=T)
     got_g, got_l = grads.cpu().numpy().astype(np.float64), losses.cpu().numpy()[:5].astype(np.float64)
+    relu_on, acts = _rectifier_pattern(hip, spec, ws, B, T)
     rows = _host_rows(ro, flat, T, E)
     assert rows["masks"].reshape(16, T)[:, 1:].sum() >= 16, "several resets inside these sequences"
     oracle = tfgraph.TrainOracle(params, "lstm", "categorical", tfgraph.LossCfg(0.01, 0.5, 0.5, True))
     o_losses = oracle.train(2.5e-4, 0.1, rows["obs"], rows["ret"], rows["masks"].astype(bool), rows["act"], rows["val"],
                             _normalised(rows["adv"], stats.cpu().numpy()[0]), rows["nlp"],
-                            states=ro["states"][envs.long()].cpu().numpy(), normalize=False)
+                            states=ro["states"][envs.long()].cpu().numpy(), normalize=False, relu_on=relu_on)
+    _check_activations(oracle, acts)
     np.testing.assert_allclose(got_l, o_losses, rtol=5e-5, atol=1e-7)
     want = np.concatenate([oracle.last_grads[name].numpy().ravel() for name, _, _ in spec.vars])
     _check_grads(spec, got_g, want, "16 envs x 128 steps vs oracle")
