@@ -13,7 +13,8 @@ import torch  # noqa: F401  (loads the process's HIP runtime before ours resolve
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libppo2hip.so")
 
-OK, EINVAL, ENOSPACE, EUNSUPPORTED = 0, -1, -2, -3
+OK, EINVAL, ENOSPACE, EUNSUPPORTED, ECOMM = 0, -1, -2, -3, -4
+UNIQUE_ID_BYTES = 128
 POLICY_MLP, POLICY_CNN, POLICY_CNN_LSTM, POLICY_CNN_LNLSTM = 0, 1, 2, 3
 DIST_GAUSSIAN, DIST_CATEGORICAL = 0, 1
 ORDER_FORK, ORDER_UPSTREAM = 0, 1
@@ -104,6 +105,18 @@ _SIGS = {
                                   c_double, c_double, _P, _P]),
     "ppo2hip_adam_step_static": (c_int, [_P, _P, _P, _P, c_int64, c_double, c_int64, c_double, c_double, c_double,
                                          c_double, c_double, _P, _P]),
+    "ppo2hip_comm_unique_id": (c_int, [_P]),
+    "ppo2hip_comm_create": (c_void_p, [_P, c_int, c_int]),
+    "ppo2hip_comm_destroy": (None, [c_void_p]),
+    "ppo2hip_comm_rank": (c_int, [c_void_p]),
+    "ppo2hip_comm_size": (c_int, [c_void_p]),
+    "ppo2hip_allreduce_grads": (c_int, [c_void_p, _P, c_int64, _P]),
+    "ppo2hip_allreduce_f64": (c_int, [c_void_p, _P, c_int64, _P]),
+    "ppo2hip_bcast_params": (c_int, [c_void_p, _P, c_int64, c_int, _P]),
+    "ppo2hip_replica_checksum": (c_int, [c_void_p, _P, c_int64, _P, _P, _P]),
+    "ppo2hip_ppo_epoch_dp": (c_int, [POINTER(PolicyDesc), POINTER(LossDesc), _P, _P, _P, _P, POINTER(Rollout), _P, c_int64,
+                                     c_int64, _P, c_float, c_double, c_int64, c_double, c_double, c_double, c_double, _P,
+                                     _P, c_size_t, _P, c_void_p, c_double, _P]),
     "ppo2hip_gemm_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
 }
 

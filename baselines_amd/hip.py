@@ -666,9 +666,63 @@ def adam_step(params, grads, m, v, lr, t, scratch, max_grad_norm=0.0, grad_scale
           "adam_step")
 
 
+class NativeComm:
+    """ppo2hip_comm: the library's own RCCL communicator (one per process, on the current device).  ``unique_id``
+    None makes a single-rank communicator that touches no collective library."""
+
+    def __init__(self, unique_id, rank, size):
+        if unique_id is not None and len(unique_id) != _lib.UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % _lib.UNIQUE_ID_BYTES)
+        buf = ctypes.create_string_buffer(bytes(unique_id), _lib.UNIQUE_ID_BYTES) if unique_id is not None else None
+        self._h = lib.ppo2hip_comm_create(buf, int(rank), int(size))
+        if not self._h:
+            check(_lib.ECOMM, "comm_create")
+        self.rank, self.size = int(rank), int(size)
+        self._digest_ws = None
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        check(lib.ppo2hip_comm_unique_id(buf), "comm_unique_id")
+        return buf.raw
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.ppo2hip_comm_destroy(h)
+
+    def allreduce_sum_(self, t):
+        if not t.is_cuda or not t.is_contiguous():
+            raise TypeError("allreduce needs a contiguous device tensor")
+        if t.dtype == torch.float32:
+            check(lib.ppo2hip_allreduce_grads(self._h, _ptr(t), t.numel(), _stream()), "allreduce_grads")
+        elif t.dtype == torch.float64:
+            check(lib.ppo2hip_allreduce_f64(self._h, _ptr(t), t.numel(), _stream()), "allreduce_f64")
+        else:
+            raise TypeError("allreduce carries float32 or float64")
+        return t
+
+    def bcast_(self, t, root=0):
+        _dev(t, torch.float32, "params")
+        check(lib.ppo2hip_bcast_params(self._h, _ptr(t), t.numel(), int(root), _stream()), "bcast_params")
+        return t
+
+    def replica_checksum(self, theta):
+        """Queues the digest exchange; returns a device int32 tensor that becomes 1 (replicas bit-identical) or 0."""
+        _dev(theta, torch.float32, "params")
+        if self._digest_ws is None:
+            self._digest_ws = torch.zeros(4, dtype=torch.int64, device=theta.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=theta.device)
+        check(lib.ppo2hip_replica_checksum(self._h, _ptr(theta), theta.numel(), _ptr(self._digest_ws), _ptr(flag), _stream()),
+              "replica_checksum")
+        return flag
+
+
 def ppo_epoch(spec, loss_desc, params, grads, m, v, rollout, idx, nbatch_train, stats, cliprange, lr, t_first,
-              losses, workspace, adam_scratch, max_grad_norm=0.0, beta1=0.9, beta2=0.999, epsilon=1e-5):
-    """All minibatches of one epoch, gradient + Adam each, in one library call (single process)."""
+              losses, workspace, adam_scratch, max_grad_norm=0.0, beta1=0.9, beta2=0.999, epsilon=1e-5, comm=None,
+              grad_scale=1.0):
+    """All minibatches of one epoch, gradient + Adam each, in one library call; with ``comm`` (a NativeComm) the
+    gradient arena is all-reduced over the ranks between the two and scaled by ``grad_scale``."""
     for x, name in ((params, "params"), (grads, "grads"), (m, "m"), (v, "v"), (losses, "losses")):
         _dev(x, torch.float32, name)
     _dev(idx, torch.int32, "idx")
@@ -689,6 +743,13 @@ def ppo_epoch(spec, loss_desc, params, grads, m, v, rollout, idx, nbatch_train, 
         raise ValueError("grad workspace too small")
     if adam_scratch.numel() * adam_scratch.element_size() < lib.ppo2hip_adam_scratch_bytes(P):
         raise ValueError("adam scratch too small")
+    if comm is not None:
+        check(lib.ppo2hip_ppo_epoch_dp(ctypes.byref(spec.desc), ctypes.byref(loss_desc), _ptr(params), _ptr(grads), _ptr(m),
+                                       _ptr(v), ctypes.byref(rollout.c), _ptr(idx), N, int(nbatch_train), _ptr(stats),
+                                       float(cliprange), float(lr), int(t_first), beta1, beta2, epsilon,
+                                       float(max_grad_norm or 0.0), _ptr(losses), _ptr(workspace), have, _ptr(adam_scratch),
+                                       comm._h, float(grad_scale), _stream()), "ppo_epoch_dp")
+        return
     check(lib.ppo2hip_ppo_epoch(ctypes.byref(spec.desc), ctypes.byref(loss_desc), _ptr(params), _ptr(grads), _ptr(m),
                                 _ptr(v), ctypes.byref(rollout.c), _ptr(idx), N, int(nbatch_train), _ptr(stats),
                                 float(cliprange), float(lr), int(t_first), beta1, beta2, epsilon,

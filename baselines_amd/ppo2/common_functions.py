@@ -109,6 +109,8 @@ class Model(object):
         """All-reduce (data parallel) + clip + Adam on the gradient arena."""
         scale = 1.0
         if self.comm is not None and self.comm.size > 1:
+            if self.adam_t % 100 == 0:       # MpiAdam.update, baselines/common/mpi_adam.py:22-23
+                self.comm.check_synced(self.arena.theta, wait=False)
             self.comm.allreduce_sum_(self.grads)
             scale = self.comm.grad_scale
         self.adam_t += 1
@@ -275,11 +277,15 @@ class Model(object):
                 d_idx = torch.from_numpy(flat).to(self.device)
                 d_envs = torch.from_numpy(envinds.copy()).to(self.device)
             stats = hip.adv_stats(ro.advs, d_idx, nbatch_train, nmb, T, E, stat_ws)
-            if comm is None and not spec.recurrent and events is None:
-                # single process: the whole epoch (gradient + Adam per minibatch) is one library call
+            native = comm.native() if comm is not None else None
+            if (comm is None or native is not None) and not spec.recurrent and events is None:
+                # the whole epoch (gradient, all-reduce over the ranks, Adam per minibatch) is one library call
+                if comm is not None and -(-self.adam_t // 100) * 100 < self.adam_t + nmb:
+                    comm.check_synced(self.arena.theta, wait=False)      # an Adam step count of this epoch is a multiple of 100
                 hip.ppo_epoch(spec, self.loss_desc, self.arena.theta, self.grads, self.adam_m, self.adam_v, rref, d_idx,
                               nbatch_train, stats, cliprange, lr, self.adam_t + 1, self._losses[row:row + nmb], ws,
-                              self._adam_scratch, max_grad_norm=self.max_grad_norm)
+                              self._adam_scratch, max_grad_norm=self.max_grad_norm, comm=native,
+                              grad_scale=comm.grad_scale if comm is not None else 1.0)
                 self.adam_t += nmb
                 row += nmb
                 done = torch.cuda.Event()
@@ -316,6 +322,7 @@ class Model(object):
         out = hip.row_mean(self._losses, total, 5, 1.0 / (total * (comm.size if comm is not None else 1)))
         if comm is not None:
             comm.allreduce_sum_(out)
+            comm.poll_checks()
         queued = torch.cuda.Event()
         queued.record(main)
         inflight.append(queued)

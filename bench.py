@@ -202,10 +202,22 @@ def main():
     args = ap.parse_args()
     cfg = WORKLOADS[args.workload]
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started bare with --gpus N: this process becomes the launcher of N fresh rank processes (one per GPU) and
+        # has not touched the GPU itself; it passes their output through and exits with their status
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1) and world > 1:
+    if world != max(args.gpus, 1):
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     # PPO2HIP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share
     # devices, gradients staged through the host); the measured configuration is one rank per GPU over RCCL

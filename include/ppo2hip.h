@@ -29,6 +29,7 @@ extern "C" {
 #define PPO2HIP_EINVAL (-1)    /* bad argument (shape, null pointer, unsupported size) */
 #define PPO2HIP_ENOSPACE (-2)  /* workspace too small */
 #define PPO2HIP_EUNSUPPORTED (-3)
+#define PPO2HIP_ECOMM (-4)     /* the collective library (RCCL) is missing or reported an error */
 
 int ppo2hip_version(void);
 const char *ppo2hip_last_error(void);
@@ -369,6 +370,52 @@ int ppo2hip_ppo_epoch(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *
                       float cliprange, double lr, int64_t t_first, double beta1, double beta2,
                       double epsilon, double max_grad_norm, float *losses, void *workspace,
                       size_t workspace_bytes, void *adam_scratch, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Data-parallel exchange (one process per GPU, RCCL over xGMI)
+ * ---------------------------------------------------------------------- */
+
+/* The communicator that stands where MpiAdam holds `MPI.COMM_WORLD`, baselines/common/mpi_adam.py:19.
+ * Rank 0 draws a unique id (HOST, PPO2HIP_UNIQUE_ID_BYTES bytes) and the host code hands it to every rank by
+ * whatever channel it has (a torch.distributed store, a file, MPI); each rank then calls ppo2hip_comm_create
+ * with ITS GPU current.  unique_id NULL is allowed for size 1: no collective library is touched.  Returns NULL
+ * on failure (ppo2hip_last_error() says why).  One communicator per process; calls on it are not re-entrant. */
+#define PPO2HIP_UNIQUE_ID_BYTES 128
+typedef struct ppo2hip_comm ppo2hip_comm;
+int ppo2hip_comm_unique_id(void *id_out);
+ppo2hip_comm *ppo2hip_comm_create(const void *unique_id, int rank, int size);
+void ppo2hip_comm_destroy(ppo2hip_comm *comm);
+int ppo2hip_comm_rank(const ppo2hip_comm *comm);
+int ppo2hip_comm_size(const ppo2hip_comm *comm);
+
+/* `comm.Allreduce(localg, globalg, op=MPI.SUM)` of MpiAdam.update, baselines/common/mpi_adam.py:24-26, in place on
+ * the flat float32 gradient arena (DEVICE), queued on `stream`; the division by the number of ranks (:27-28) is
+ * the `grad_scale` of ppo2hip_adam_step.  comm NULL or of size 1: nothing to do. */
+int ppo2hip_allreduce_grads(ppo2hip_comm *comm, float *buf, int64_t n, void *stream);
+/* SUM all-reduce of float64 totals in place (DEVICE): the moment vectors [sum | sumsq | count] of
+ * baselines/common/mpi_moments.py:12-17 and baselines/common/mpi_running_mean_std.py:37-43, and the
+ * {sum a, sum a^2, n} rows of ppo2hip_adv_stats when every rank draws the same global minibatch. */
+int ppo2hip_allreduce_f64(ppo2hip_comm *comm, double *buf, int64_t n, void *stream);
+/* `comm.Bcast(theta, root=0)` of MpiAdam.sync, baselines/common/mpi_adam.py:37-40, in place (DEVICE). */
+int ppo2hip_bcast_params(ppo2hip_comm *comm, float *buf, int64_t n, int root, void *stream);
+/* MpiAdam.check_synced, baselines/common/mpi_adam.py:42-50 (every rank's parameters must equal rank 0's exactly),
+ * without moving the parameters: each rank digests the bits of its arena into two 64-bit sums, the ranks MAX-reduce
+ * {h, ~h}, and *synced (DEVICE int32) becomes 1 when max == min for both digests, else 0.
+ *   workspace : DEVICE, 32 bytes, 8-byte aligned */
+int ppo2hip_replica_checksum(ppo2hip_comm *comm, const float *params, int64_t n, void *workspace, int32_t *synced,
+                             void *stream);
+
+/* ppo2hip_ppo_epoch for a data-parallel job: between each minibatch's gradient and its optimiser step the gradient
+ * arena is SUM-all-reduced over `comm` and scaled by `grad_scale` (1/size: MpiAdam.update, baselines/common/
+ * mpi_adam.py:24-28), all queued on `stream` with no host synchronisation, so an epoch stays one library call.
+ * Every rank must make the same sequence of calls (same N / nbatch_train). */
+int ppo2hip_ppo_epoch_dp(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss, float *params,
+                         float *grads, float *adam_m, float *adam_v, const ppo2hip_rollout *rollout,
+                         const int32_t *idx, int64_t N, int64_t nbatch_train, const double *stats,
+                         float cliprange, double lr, int64_t t_first, double beta1, double beta2,
+                         double epsilon, double max_grad_norm, float *losses, void *workspace,
+                         size_t workspace_bytes, void *adam_scratch, ppo2hip_comm *comm, double grad_scale,
+                         void *stream);
 
 /* out[c] = scale * sum_r rows[r*stride + c] for c < ncols (<= 16): the mean of the per-minibatch
  * loss rows that learn reports, baselines/ppo2/ppo2.py:139 (scale = 1/nrows; data-parallel runs

@@ -98,17 +98,7 @@ def _worker(rank, world, port, mode, out):
 
 
 def _run(mode):
-    ctx = mp.get_context("spawn")
-    out = ctx.SimpleQueue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = out.get()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    return res
+    return util.run_ranks(_worker, 2, (mode,))
 
 
 def test_global_mode_reproduces_single_process_update():

@@ -31,19 +31,16 @@ def test_bench_line():
 
 
 def test_bench_two_ranks_rehearsal():
-    """The launch the driver uses for N > 1 (torch.distributed.run, one process per rank), rehearsed with two
+    """The N > 1 launch (torch.distributed.run, one process per rank; bench.py starts it itself when it is run without
+    a launcher), rehearsed with two
     ranks on this box's one GPU: gloo carries the gradients through the host (PPO2HIP_BENCH_BACKEND=gloo), so
     the throughput means nothing, but rank handling, barriers, the max-over-ranks clock and the single JSON
     line from rank 0 are the measured path's."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, PPO2HIP_BENCH_BACKEND="gloo")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-                          "--warmup", "1"], cwd=ROOT, env=env, check=True, capture_output=True, text=True, timeout=280).stdout
+    env.pop("WORLD_SIZE", None)
+    # started bare, as `python bench.py --gpus 2`: the script launches its own two rank processes
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         cwd=ROOT, env=env, check=True, capture_output=True, text=True, timeout=280).stdout
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out
     d = json.loads(lines[0])

@@ -66,19 +66,7 @@ def test_two_ranks_reproduce_single_process_update():
     assert torch.cuda.is_available()
     params, ro = _data()
     l1, t1 = _run_model(params, ro, 0, E, None, 5)
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    out = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    l2, t2 = out.get()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    l2, t2 = util.run_ranks(_worker, 2)
     np.testing.assert_allclose(l2, l1, rtol=5e-5, atol=1e-7)
     moved = np.abs(t1 - util.flatten_params(params, type("S", (), {"nparams": t1.size, "vars": _vars()})())).max()
     assert np.abs(t1 - t2).max() <= 2e-6, np.abs(t1 - t2).max()
@@ -119,19 +107,7 @@ def test_mpi_running_mean_std_two_ranks():
     """The reference's own distributed check (baselines/common/mpi_running_mean_std.py:85-107): two ranks fed
     different data end with the statistics of the concatenated data."""
     from oracle import envwrap
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context("spawn")
-    out = ctx.SimpleQueue()
-    procs = [ctx.Process(target=_rms_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    mean, std, state = out.get()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    mean, std, state = util.run_ranks(_rms_worker, 2)
     _, everything = _rms_data(0)
     allx = np.concatenate(everything)
     # the reference compares with allclose against mean / std of the whole; std floors its variance at 1e-2

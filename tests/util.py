@@ -104,3 +104,49 @@ def synthetic_cnn_rollout(rng, T, E, hwc, nact, params, kind="cnn", nlstm=0, nlp
     rewards = rng.randn(T, E, 1).astype(np.float32)
     return dict(obs=obs, actions=actions, neglogpacs=nlp, values=values, rewards=rewards, dones=dones,
                 last_values=rng.randn(E, 1).astype(np.float32), last_dones=rng.rand(E) < 0.1, states=states0)
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def run_ranks(target, world, args=(), timeout=240):
+    """Spawn ``world`` processes running ``target(rank, world, port, *args, out)`` and return what rank 0 puts on
+    ``out``.  The queue is polled against a deadline and the children's exit codes, so a rank that dies before
+    reporting (import error, failed rendezvous, an assertion) fails the test at once instead of blocking it."""
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (out,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    deadline = time.time() + timeout
+    res = None
+    try:
+        while res is None:
+            if not out.empty():
+                res = out.get()
+                break
+            dead = [p for p in procs if p.exitcode not in (None, 0)]
+            if dead:
+                raise AssertionError("rank process exited with code %s before reporting" % dead[0].exitcode)
+            if all(p.exitcode == 0 for p in procs) and out.empty():
+                raise AssertionError("all ranks exited without a result")
+            if time.time() > deadline:
+                raise AssertionError("ranks did not report within %d s" % timeout)
+            time.sleep(0.05)
+        for p in procs:
+            p.join(max(1.0, deadline - time.time()))
+            assert p.exitcode == 0, "rank exited with code %s" % p.exitcode
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    return res
