@@ -104,7 +104,8 @@ struct FusedImage {
     int s_w1, s_w2, s_wh, s_bh, head_cols;
     int s_logstd;   // where the image holds the summed logstd gradient, or -1: it is in the loss partial rows
 };
-int fused_finalize(const FusedImage &im, const float *slabs, int nslabs, const double *lpart, int nloss_rows,
+// slabs: nslabs_policy gradient images of the policy trunk, then nslabs_value of the value trunk
+int fused_finalize(const FusedImage &im, const float *slabs, int nslabs_policy, int nslabs_value, const double *lpart, int nloss_rows,
                    const ppo2hip_policy_desc &d, const FusedOffsets &fo, double inv_count, float *grads, float *losses,
                    hipStream_t s);
 bool mlp_fused16_supported(const ppo2hip_policy_desc &d);

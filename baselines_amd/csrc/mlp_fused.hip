@@ -529,7 +529,7 @@ struct SegTable {
 };
 struct FinalizeArgs {
     const float *slabs;
-    int nslabs;
+    int nslabs[2];           // gradient images of the policy trunk, then of the value trunk (laid out in that order)
     int64_t slab_elems;
     SegTable t;
     int nseg_blocks, nhead_blocks;
@@ -551,6 +551,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(Finaliz
     if (b < f.nseg_blocks + f.nhead_blocks) {
         const float *p = nullptr;
         float *out = nullptr;
+        int nz = 0;
         if (b < f.nseg_blocks) {
             int seg = 0;
             int64_t base = 0;
@@ -561,7 +562,8 @@ __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(Finaliz
             }
             const int64_t e = (int64_t)b * 64 + lane - base;
             if (seg < f.t.n && e < f.t.size[seg]) {
-                p = f.slabs + (int64_t)f.t.trunk[seg] * f.nslabs * f.slab_elems + f.t.src[seg] + e;
+                p = f.slabs + (int64_t)(f.t.trunk[seg] ? f.nslabs[0] : 0) * f.slab_elems + f.t.src[seg] + e;
+                nz = f.nslabs[f.t.trunk[seg]];
                 out = f.grads + f.t.dst[seg] + e;
             }
         } else {
@@ -577,16 +579,18 @@ __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(Finaliz
             if (e < (trunk ? nv : na)) {
                 const int k = e / O, o = e - k * O;
                 const int src = k < f.H2 ? f.s_wh + k * f.head_cols + o : f.s_bh + o;
-                p = f.slabs + (int64_t)trunk * f.nslabs * f.slab_elems + src;
+                p = f.slabs + (int64_t)(trunk ? f.nslabs[0] : 0) * f.slab_elems + src;
+                nz = f.nslabs[trunk];
                 out = f.grads + (trunk ? f.v_dst : f.a_dst) + e;
             } else if (!trunk && e < na + nls) {
                 p = f.slabs + f.s_logstd + (e - na);
+                nz = f.nslabs[0];
                 out = f.dlogstd + (e - na);
             }
         }
         float s = 0.f;
         if (p)
-            for (int z = grp; z < f.nslabs; z += kFinGroups) s += p[(int64_t)z * f.slab_elems];
+            for (int z = grp; z < nz; z += kFinGroups) s += p[(int64_t)z * f.slab_elems];
         part[grp][lane] = s;
         __syncthreads();
         if (grp == 0 && out) {
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(Finaliz
     }
 }
 
-int fused_finalize(const FusedImage &im, const float *slabs, int nslabs, const double *lpart, int nloss_rows,
+int fused_finalize(const FusedImage &im, const float *slabs, int nslabs_policy, int nslabs_value, const double *lpart, int nloss_rows,
                    const ppo2hip_policy_desc &d, const FusedOffsets &fo, double inv_count, float *grads, float *losses,
                    hipStream_t s) {
     const int H1 = d.hidden1, H2 = d.hidden2, D = d.ob_dim, A = d.ac_dim, R = d.nvalue;
@@ -629,7 +633,7 @@ int fused_finalize(const FusedImage &im, const float *slabs, int nslabs, const d
     int64_t blocks = 0;
     for (int i = 0; i < fa.t.n; i++) blocks += (fa.t.size[i] + 63) / 64;
     const bool gauss = d.dist == PPO2HIP_DIST_GAUSSIAN;
-    fa.slabs = slabs; fa.nslabs = nslabs; fa.slab_elems = im.slab_elems;
+    fa.slabs = slabs; fa.nslabs[0] = nslabs_policy; fa.nslabs[1] = nslabs_value; fa.slab_elems = im.slab_elems;
     fa.nseg_blocks = (int)blocks;
     fa.nhead_blocks = ((H2 + 1) * A + (gauss && im.s_logstd >= 0 ? A : 0) + 63) / 64 + ((H2 + 1) * R + 63) / 64;
     fa.s_wh = im.s_wh; fa.s_bh = im.s_bh; fa.s_logstd = im.s_logstd; fa.H2 = H2; fa.A = A; fa.R = R; fa.head_cols = im.head_cols;
@@ -687,7 +691,7 @@ int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, co
 
     FusedImage im;
     im.slab_elems = L::SLAB; im.s_w1 = L::S_W1; im.s_w2 = L::S_W2; im.s_wh = L::S_WH; im.s_bh = L::S_BH; im.head_cols = 32; im.s_logstd = -1;
-    return fused_finalize(im, slabs, grid / 2, lpart, grid, d, fo, inv_count, grads, losses, s);
+    return fused_finalize(im, slabs, grid / 2, grid / 2, lpart, grid, d, fo, inv_count, grads, losses, s);
 }
 
 }  // namespace ppo2hip

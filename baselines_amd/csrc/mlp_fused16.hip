@@ -23,6 +23,8 @@
 // 16) spreads the four 16-lane groups of a ds_read_b128 over distinct 16-byte bank slots.
 // Head rows are permuted (accumulator row 4 lk + r holds output lk + 4 r) so that outputs
 // 0..O-1 occupy the first ceil(O / 4) registers and the input gradient skips the rest.
+#include <cstdlib>
+
 #include "gemm_core.hpp"
 #include "kernels.hpp"
 
@@ -44,7 +46,8 @@ constexpr int B2 = W2TP + H * H;               // [64]
 constexpr int WHP = B2 + H;                    // [16 k4][16 rows][4 r]       accumulator row -> output (row >> 2) + 4 (row & 3)
 constexpr int WHTP = WHP + H * 16;             // [4 lk][64 units][4 r]       output = lk + 4 r
 constexpr int BHP = WHTP + H * 16;             // [16 rows]
-constexpr int WEIGHTS = BHP + 16;
+constexpr int WHV = BHP + 16;                  // [64 units]  the single head column of a one-output value trunk
+constexpr int WEIGHTS = WHV + H;
 // per-wave tiles (floats), all [rows][16 samples] in the swizzled column order
 constexpr int XA = 0;                          // [32 features]   row D = ones, rows above D = zeros
 constexpr int TA = XA + 32 * 16;               // [64 units]      h1, then d(loss)/d(pre-activation 1)
@@ -80,7 +83,10 @@ struct Fused16Args {
     int64_t a_w1, a_w2, a_wh, v_w1, v_w2, v_wh, logstd_off;
     int D, A, R, dist, upstream;
     float cliprange, ent_coef, vf_coef, inv_count;
-    float *slabs;            // [2 trunks][nwg_per_trunk][SLAB]
+    unsigned div_magic;      // smp / T = (t + ((smp - t) >> div_sh1)) >> div_sh2 with t = mulhi(div_magic, smp)
+    int div_sh1, div_sh2;
+    int nwg_policy;          // workgroups 0 .. nwg_policy-1 run the policy trunk, the rest the value trunk
+    float *slabs;            // [workgroup][SLAB]: the policy trunk's images, then the value trunk's
     double *loss_partial;    // [gridDim.x][kLossStride]
 };
 
@@ -98,15 +104,33 @@ __device__ __forceinline__ int buf_i32(rsrc_t r, unsigned byte_off) {
     return (int)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
 }
 
-__device__ __forceinline__ float fast_tanh16(float x) {
-    // tanh x = 1 - 2 / (exp(2x) + 1); v_exp_f32 and v_rcp_f32 are 1 ulp: |error| <= ~1.5e-7 absolute
-    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+// tanh of a pre-activation that arrives already multiplied by kTanhScale = 2 log2(e) (the forward copies of the
+// weights and biases carry the factor): tanh z = 1 - 2 / (2^(kTanhScale z) + 1).  v_exp_f32 and v_rcp_f32 are 1 ulp:
+// |error| <= ~1.5e-7 absolute.  The add and the final fma run on register pairs (v_pk_add_f32 / v_pk_fma_f32: two
+// values per lane and issue slot); with the fp32 matrix products sharing the vector ALUs, every slot saved here is a
+// slot for them.
+constexpr float kTanhScale = 2.8853900817779268f;
+__device__ __forceinline__ f32x4 tanh_prescaled4(f32x4 z) {
+    f32x4 t;
+#pragma unroll
+    for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_exp2f(z[r]);
+    t = t + 1.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_rcpf(t[r]);
+    return 1.0f - 2.0f * t;
 }
+// MINUS dz * tanh'(z) from the saved activation t = tanh z, on register pairs: dz (t t - 1) is a v_pk_fma_f32 with
+// the inline constant -1 and a v_pk_mul_f32, where 1 - t t would first have to negate t.  The backward pass applies
+// it once per layer, so the sign returns at layer 1; what is built from the layer-2 gradient alone (dW2, db2) is
+// accumulated negated and has its sign put right when the images are written out.
+__device__ __forceinline__ f32x4 neg_times_tanh_grad4(f32x4 dz, f32x4 t) { return dz * (t * t - 1.0f); }
 
 // KQ = k-steps of layer 1 (ob_dim + 1 <= 4 KQ; also the observation registers per lane);
-// WIDE = ob_dim + 1 > 16 (second block of dW1 rows)
-template <int KQ, bool WIDE>
+// WIDE = ob_dim + 1 > 16 with the second block of dW1 rows as matrix products;
+// XV = 1 or 2: ob_dim = 15 + XV, the one or two feature rows past the first sixteen (x16 if any, and the ones row)
+//      get their weight gradients from vector fmas on the operand chunks the first block reads anyway — a second
+//      16-row block of products would multiply fourteen rows of zeros.
+template <int KQ, bool WIDE, int XV>
 __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Args g) {
     using namespace f16;
     __shared__ __attribute__((aligned(16))) float lds[TOTAL];
@@ -115,15 +139,59 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const bool is_value = (blockIdx.x & 1) != 0;
-    const int nwg_trunk = gridDim.x >> 1;
-    const int wg_in_trunk = blockIdx.x >> 1;
+    const bool is_value = (int)blockIdx.x >= g.nwg_policy;
+    const int nwg_trunk = is_value ? (int)gridDim.x - g.nwg_policy : g.nwg_policy;
+    const int wg_in_trunk = is_value ? (int)blockIdx.x - g.nwg_policy : (int)blockIdx.x;
     const int64_t o_w1 = is_value ? g.v_w1 : g.a_w1, o_w2 = is_value ? g.v_w2 : g.a_w2, o_wh = is_value ? g.v_wh : g.a_wh;
     const int D = g.D;
     const int O = is_value ? g.R : g.A;
     const int nr = (O + 3) >> 2;                      // head registers in use
     const bool gaussian = g.dist == PPO2HIP_DIST_GAUSSIAN;
+    // A value trunk with ONE output runs its head on the vector ALUs: the 16-row matrix shape would spend 36
+    // products per tile (forward, weight gradient, input gradient) on one useful row in sixteen.
+    const bool vhead = is_value && g.R == 1;
 
+    // ---- first tiles' gather goes out before anything else: two dependent round trips (index, then the row it names)
+    //      that the weight staging below covers --------------------------------------------------------------------
+    const int64_t ntiles = (g.B + 15) >> 4;
+    // Tiles are dealt to SIMDs, not to waves: waves w and w + 4 share SIMD w (and its vector / matrix ALUs), so what
+    // bounds a workgroup is the tile count of its busiest SIMD.  SIMD q of the trunk's 4 nwg_trunk takes tiles
+    // q, q + 4 nwg_trunk, ...; its two waves alternate over that list, so an odd count costs half a tile per wave, not one.
+    const int64_t nsimd = (int64_t)nwg_trunk * 4;
+    const int64_t wave_global = (int64_t)wg_in_trunk * 4 + (wave & 3) + nsimd * (wave >> 2);
+    const int64_t wave_stride = 2 * nsimd;
+
+    const rsrc_t r_obs = make_rsrc(g.obs, g.n * D * 4);
+    const rsrc_t r_act = make_rsrc(g.actions, gaussian ? g.n * g.A * 4 : g.n * 4);
+    const rsrc_t r_ret = make_rsrc(g.returns, g.n * g.R * 4), r_val = make_rsrc(g.values, g.n * g.R * 4);
+    const rsrc_t r_nlp = make_rsrc(g.neglogpacs, g.n * 4), r_adv = make_rsrc(g.advs, g.n * (g.adv_f64 ? 8 : 4));
+    const rsrc_t r_idx = make_rsrc(g.idx, g.idx ? g.B * 4 : 0);
+
+    // rollout row of this lane's sample in a tile (row 0 stands in for samples past the end: the
+    // index load past the list's end returns 0); sample numbers are int32, so rows are too
+    auto tile_row = [&](int64_t tile) -> int {
+        const int64_t i = tile * 16 + li;
+        int smp;
+        if (g.idx) smp = buf_i32(r_idx, (unsigned)(i < g.B ? i : g.B) * 4u);
+        else smp = i < g.B ? (int)i : 0;
+        if (g.T == 0) return smp;
+        // env = smp / T by multiplication (Granlund-Montgomery round-up form; magic and shifts from the host)
+        const unsigned n = (unsigned)smp, t = __umulhi(g.div_magic, n);
+        const int env = (int)((t + ((n - t) >> g.div_sh1)) >> g.div_sh2);
+        return (smp - env * g.T) * g.E + env;
+    };
+    // this lane's share of its sample's observation row: features lk + 4 u (reads past the row's
+    // end bring the next row's values or 0, and are parked in the spare row below)
+    float xr[KQ];
+    auto load_obs = [&](int row) {
+        const unsigned base = (unsigned)row * (unsigned)(D * 4) + (unsigned)(lk * 4);
+#pragma unroll
+        for (int u = 0; u < KQ; u++) xr[u] = buf_f32(r_obs, base + 16u * u);
+    };
+
+    const float sc = g.inv_count / (float)g.R, rR = 1.f / (float)g.R;      // value-loss scalings
+    int row = tile_row(wave_global), row_next = tile_row(wave_global + wave_stride);
+    load_obs(row);
     // ---- stage this trunk's weights in the packed layouts ------------------------------------
     {
         const float *P = g.params;
@@ -132,17 +200,17 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
             const int e = tid + u * kThreads;
             const int k = e >> 6, j = e & 63;                              // input row k, unit j (coalesced read)
             const float v = k <= D ? P[o_w1 + (int64_t)k * H + j] : 0.f;   // rows 0..D-1 weights, row D = bias
-            lds[W1P + k * 64 + (j & 15) * 4 + (j >> 4)] = v;
+            lds[W1P + k * 64 + (j & 15) * 4 + (j >> 4)] = kTanhScale * v;  // forward copy: pre-activations arrive scaled for tanh
         }
 #pragma unroll
         for (int u = 0; u < H * H / kThreads; u++) {
             const int e = tid + u * kThreads;
             const int k = e >> 6, j = e & 63;
             const float v = P[o_w2 + e];
-            lds[W2P + ((k >> 2) * 64 + j) * 4 + (k & 3)] = v;
+            lds[W2P + ((k >> 2) * 64 + j) * 4 + (k & 3)] = kTanhScale * v;     // forward copy (scaled), backward copy (as is)
             lds[W2TP + ((j >> 2) * 64 + k) * 4 + (j & 3)] = v;
         }
-        if (tid < H) lds[B2 + tid] = P[o_w2 + (int64_t)H * H + tid];
+        if (tid < H) lds[B2 + tid] = kTanhScale * P[o_w2 + (int64_t)H * H + tid];
 #pragma unroll
         for (int u = 0; u < H * 16 / kThreads; u++) {
             const int e = tid + u * kThreads;
@@ -152,11 +220,14 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
             lds[WHP + ((k >> 2) * 16 + row) * 4 + (k & 3)] = v;
             lds[WHTP + ((o & 3) * 64 + k) * 4 + (o >> 2)] = v;
         }
+        if (tid < H) lds[WHV + tid] = vhead ? P[o_wh + tid] : 0.f;
         if (tid < 16) {
             const int o = (tid >> 2) + 4 * (tid & 3);                      // output held by accumulator row tid
             lds[BHP + tid] = o < O ? P[o_wh + (int64_t)H * O + o] : 0.f;
         }
-        for (int e = tid; e < kWaves * WAVE; e += kThreads) lds[WEIGHTS + e] = 0.f;
+        // feature rows above the ones row multiply as zeros (layer 1's k padding, the second block of dW1 rows); every
+        // other tile is written whole before it is read
+        for (int e = tid; e < kWaves * 32 * 16; e += kThreads) lds[WEIGHTS + (e >> 9) * WAVE + XA + (e & 511)] = 0.f;
     }
     __syncthreads();
 
@@ -210,9 +281,12 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
     // ---- gradient accumulators (registers, whole launch) ------------------------------------
     f32x4 dW1[2][HB], dW2[HB][HB], dWh[HB];
     float db2[HB], dbh = 0.f;
+    float dx16[HB], db1[HB];          // XV: rows 16 (feature x16) and ob_dim (ones) of dW1, per lane over its four samples
 #pragma unroll
     for (int a = 0; a < HB; a++) {
         db2[a] = 0.f;
+        dx16[a] = 0.f;
+        db1[a] = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             dWh[a][r] = 0.f;
@@ -225,38 +299,6 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
     // per-lane loss sums stay short (one term per tile): float here, double from the wave sum on
     float s_pg = 0.f, s_vf = 0.f, s_ent = 0.f, s_kl = 0.f, s_cf = 0.f;
 
-    const int64_t ntiles = (g.B + 15) >> 4;
-    const int64_t wave_global = (int64_t)wg_in_trunk * kWaves + wave;
-    const int64_t wave_stride = (int64_t)nwg_trunk * kWaves;
-
-    const rsrc_t r_obs = make_rsrc(g.obs, g.n * D * 4);
-    const rsrc_t r_act = make_rsrc(g.actions, gaussian ? g.n * g.A * 4 : g.n * 4);
-    const rsrc_t r_ret = make_rsrc(g.returns, g.n * g.R * 4), r_val = make_rsrc(g.values, g.n * g.R * 4);
-    const rsrc_t r_nlp = make_rsrc(g.neglogpacs, g.n * 4), r_adv = make_rsrc(g.advs, g.n * (g.adv_f64 ? 8 : 4));
-    const rsrc_t r_idx = make_rsrc(g.idx, g.idx ? g.B * 4 : 0);
-
-    // rollout row of this lane's sample in a tile (row 0 stands in for samples past the end: the
-    // index load past the list's end returns 0); sample numbers are int32, so rows are too
-    auto tile_row = [&](int64_t tile) -> int {
-        const int64_t i = tile * 16 + li;
-        int smp;
-        if (g.idx) smp = buf_i32(r_idx, (unsigned)(i < g.B ? i : g.B) * 4u);
-        else smp = i < g.B ? (int)i : 0;
-        if (g.T == 0) return smp;
-        const int env = smp / g.T;
-        return (smp - env * g.T) * g.E + env;
-    };
-    // this lane's share of its sample's observation row: features lk + 4 u (reads past the row's
-    // end bring the next row's values or 0, and are parked in the spare row below)
-    float xr[KQ];
-    auto load_obs = [&](int row) {
-        const unsigned base = (unsigned)row * (unsigned)(D * 4) + (unsigned)(lk * 4);
-#pragma unroll
-        for (int u = 0; u < KQ; u++) xr[u] = buf_f32(r_obs, base + 16u * u);
-    };
-
-    int row = tile_row(wave_global), row_next = tile_row(wave_global + wave_stride);
-    load_obs(row);
 
     for (int64_t tile = wave_global; tile < ntiles; tile += wave_stride) {
         const bool live = tile * 16 + li < g.B;
@@ -288,8 +330,8 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
             } else {
                 act_i = buf_i32(r_act, (unsigned)row * 4u);
             }
-        } else {                 // value channels lk and lk + 4 (nvalue <= 8)
-            const unsigned base = (unsigned)row * (unsigned)(g.R * 4) + (unsigned)(lk * 4);
+        } else {                 // value channels lk and lk + 4 (nvalue <= 8); one-output head: every lane its sample's own
+            const unsigned base = (unsigned)row * (unsigned)(g.R * 4) + (vhead ? 0u : (unsigned)(lk * 4));
             ret[0] = buf_f32(r_ret, base);
             ret[1] = buf_f32(r_ret, base + 16u);
             oldv[0] = buf_f32(r_val, base);
@@ -323,9 +365,7 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
             }
         }
 #pragma unroll
-        for (int mb = 0; mb < HB; mb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) h1[mb][r] = fast_tanh16(h1[mb][r]);
+        for (int mb = 0; mb < HB; mb++) h1[mb] = tanh_prescaled4(h1[mb]);
 #pragma unroll
         for (int mb = 0; mb < HB; mb++)
 #pragma unroll
@@ -352,16 +392,27 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
             }
         }
 #pragma unroll
-        for (int m = 0; m < HB; m++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) h2[m][r] = fast_tanh16(h2[m][r]);
+        for (int m = 0; m < HB; m++) h2[m] = tanh_prescaled4(h2[m]);
 #pragma unroll
         for (int m = 0; m < HB; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++) tb[dpos + (16 * m + r) * 16] = h2[m][r];
 
         // ---- head: register r of lane quarter lk = output lk + 4 r ----------------------------------
-        {
+        if (vhead) {                     // this lane's 16 units of the head column
+            float p = 0.f;
+#pragma unroll
+            for (int m = 0; m < HB; m++) {
+                const f32x4 wv = LDS4(WHV + 16 * m + 4 * lk);
+#pragma unroll
+                for (int r = 0; r < 4; r++) p = fmaf(wv[r], h2[m][r], p);
+            }
+            p += __shfl_xor(p, 16, 64);      // the four lane quarters hold disjoint units of sample li
+            p += __shfl_xor(p, 32, 64);
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[r] = 0.f;
+            out[0] = p + lds[BHP];
+        } else {
             f32x4 w[HB];
             out = LDS4(BHP + 4 * lk);
 #pragma unroll
@@ -456,10 +507,12 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
                 }
             }
         } else {
-            const float sc = g.inv_count / (float)g.R, rR = 1.f / (float)g.R;
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                if (lk + 4 * r < g.R && live) {
+                // one-output head: all four lane quarters hold the sample's value and need its gradient; quarter 0 books the loss
+                const bool mine = vhead ? r == 0 : lk + 4 * r < g.R;
+                const float book = (!vhead || lk == 0) ? 1.f : 0.f;
+                if (mine && live) {
                     const float v = out[r];
                     const float e1 = v - ret[r];
                     if (g.upstream) {
@@ -467,23 +520,32 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
                         const float vc = oldv[r] + fminf(fmaxf(dv, -g.cliprange), g.cliprange);
                         const float e2 = vc - ret[r];
                         const float l1 = e1 * e1, l2 = e2 * e2;
-                        s_vf += 0.5f * fmaxf(l1, l2) * rR;
+                        s_vf += book * (0.5f * fmaxf(l1, l2) * rR);
                         const float gg = (l1 >= l2) ? e1 : ((dv >= -g.cliprange && dv <= g.cliprange) ? e2 : 0.f);
                         dout[r] = g.vf_coef * sc * gg;
                     } else {
-                        s_vf += (e1 * e1) * rR;
+                        s_vf += book * ((e1 * e1) * rR);
                         dout[r] = 2.f * e1 * sc;
                     }
                 }
             }
         }
+        f32x4 dz2[HB];
+        const float d0 = dout[0];
+        if (vhead) {
+            // ---- one-output head on the vector ALUs: input gradient and bias gradient here, the per-lane partial weight
+            //      gradients (units 16 m + 4 lk + r, sample li; summed over the sample lanes when the images are written)
+            //      below, from the activations the tanh' step reads back anyway ------------------------------------
+#pragma unroll
+            for (int m = 0; m < HB; m++) dz2[m] = LDS4(WHV + 16 * m + 4 * lk) * d0;
+            dbh += lk == 0 ? d0 : 0.f;
+        } else {
         // output lk + 4 r is row lk + 4 r of the head tile (swz of that row = r & 2)
 #pragma unroll
         for (int r = 0; r < 4; r++) tc[(lk + 4 * r) * 16 + ((r & 2) ? c1 : c0)] = dout[r];
         __builtin_amdgcn_wave_barrier();
 
         // ---- head: weight gradient (h2^T dout; bias gradient = row sums of dout^T) -------------------
-        f32x4 dz2[HB];
         {
             f32x4 a[HB], wt[HB];
             const f32x4 b = LDS4(WEIGHTS + wave * WAVE + TC + rpos);
@@ -508,14 +570,16 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
                     for (int m = 0; m < HB; m++) dz2[m] = MFMA16(wt[m][r], dout[r], dz2[m]);
                 }
         }
+        }
         // tanh' from the activations still sitting in the tile, then the tile takes the gradient
 #pragma unroll
-        for (int m = 0; m < HB; m++)
+        for (int m = 0; m < HB; m++) {
+            f32x4 t;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float t = tb[dpos + (16 * m + r) * 16];
-                dz2[m][r] *= 1.f - t * t;
-            }
+            for (int r = 0; r < 4; r++) t[r] = tb[dpos + (16 * m + r) * 16];
+            if (vhead) dWh[m] += t * d0;
+            dz2[m] = neg_times_tanh_grad4(dz2[m], t);      // = -dz2
+        }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int m = 0; m < HB; m++)
@@ -546,12 +610,12 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
             }
         }
 #pragma unroll
-        for (int mb = 0; mb < HB; mb++)
+        for (int mb = 0; mb < HB; mb++) {
+            f32x4 t;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float t = ta[dpos + (16 * mb + r) * 16];
-                dz1[mb][r] *= 1.f - t * t;
-            }
+            for (int r = 0; r < 4; r++) t[r] = ta[dpos + (16 * mb + r) * 16];
+            dz1[mb] = neg_times_tanh_grad4(dz1[mb], t);    // -(W2 (-dz2)) tanh' = dz1
+        }
         // ---- layer 2: weight gradient (h1^T dz2 from the tiles), bias gradient from the same operand reads ---
         {
             f32x4 a[HB], b[HB];
@@ -593,6 +657,17 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
 #pragma unroll
                     for (int mj = 0; mj < HB; mj++) dW1[1][mj] = MFMA16(a1[q], b[mj][q], dW1[1][mj]);
             }
+            if (XV) {       // the ones row: sums of the same operand chunks (unit 16 mj + li, samples lk + 4 q)
+#pragma unroll
+                for (int mj = 0; mj < HB; mj++) db1[mj] += (b[mj][0] + b[mj][1]) + (b[mj][2] + b[mj][3]);
+            }
+            if (XV == 2) {  // feature row 16 (swizzle 0): its samples lk + 4 q are one 16-byte chunk
+                const f32x4 x16 = LDS4(WEIGHTS + wave * WAVE + XA + 256 + (lk << 2));
+#pragma unroll
+                for (int mj = 0; mj < HB; mj++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) dx16[mj] = fmaf(x16[q], b[mj][q], dx16[mj]);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         row = row_next;
@@ -611,42 +686,81 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
     }
 
     // ---- cross-wave reduction of the gradient images (two rounds of four), one slab per workgroup ------
+    // sums over the four lane quarters (a lane's partial covers its samples lk + 4 q only)
+    auto quarters = [](float v) {
+        v += __shfl_xor(v, 16, 64);
+        return v + __shfl_xor(v, 32, 64);
+    };
+    if (vhead) {
+        // the vector-ALU head kept one partial per sample lane: sum over the 16 lanes of each quarter
+#pragma unroll
+        for (int mi = 0; mi < HB; mi++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = dWh[mi][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+                dWh[mi][r] = v;
+            }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) dbh += __shfl_xor(dbh, o, 64);
+    }
     auto put = [&](float *img, bool add) {
         auto st = [&](int off, float v) { img[off] = add ? img[off] + v : v; };
 #pragma unroll
-        for (int f = 0; f < 2; f++)
+        for (int f = 0; f < (WIDE ? 2 : 1); f++)
 #pragma unroll
             for (int mj = 0; mj < HB; mj++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) st(S_W1 + (16 * f + 4 * lk + r) * H + 16 * mj + li, dW1[f][mj][r]);
+        if (XV) {
+#pragma unroll
+            for (int mj = 0; mj < HB; mj++) {
+                const float vb = quarters(db1[mj]);
+                if (lk == 0) st(S_W1 + (15 + XV) * H + 16 * mj + li, vb);          // the ones row = row ob_dim
+                if (XV == 2) {
+                    const float vx = quarters(dx16[mj]);
+                    if (lk == 0) st(S_W1 + 16 * H + 16 * mj + li, vx);
+                }
+            }
+        }
+        // dW2 and db2 were accumulated from -dz2 (see neg_times_tanh_grad4)
 #pragma unroll
         for (int mi = 0; mi < HB; mi++)
 #pragma unroll
             for (int mj = 0; mj < HB; mj++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) st(S_W2 + (16 * mi + 4 * lk + r) * H + 16 * mj + li, dW2[mi][mj][r]);
+                for (int r = 0; r < 4; r++) st(S_W2 + (16 * mi + 4 * lk + r) * H + 16 * mj + li, -dW2[mi][mj][r]);
+        if (vhead) {
 #pragma unroll
-        for (int mi = 0; mi < HB; mi++)
+            for (int mi = 0; mi < HB; mi++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) st(S_WH + (16 * mi + 4 * lk + r) * 16 + li, dWh[mi][r]);
+                for (int r = 0; r < 4; r++)
+                    if (li == 0) st(S_WH + (16 * mi + 4 * lk + r) * 16, dWh[mi][r]);
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < HB; mi++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) st(S_WH + (16 * mi + 4 * lk + r) * 16 + li, dWh[mi][r]);
+        }
 #pragma unroll
         for (int mj = 0; mj < HB; mj++) {
-            float v = db2[mj];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (lk == 0) st(S_B2 + 16 * mj + li, v);
+            const float v = quarters(db2[mj]);
+            if (lk == 0) st(S_B2 + 16 * mj + li, -v);
         }
-        float v = dbh;
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (lk == 0) st(S_BH + li, v);
+        const float v = quarters(dbh);
+        if (vhead) {
+            if (lane == 0) st(S_BH, v);          // quarter 0 held the sum over the samples, the others zero
+        } else if (lk == 0) {
+            st(S_BH + li, v);
+        }
     };
     __syncthreads();                                   // weights and tiles are dead: LDS holds images now
     if (wave >= 4) put(lds + (wave - 4) * SLAB, false);
     __syncthreads();
     if (wave < 4) put(lds + wave * SLAB, true);
     __syncthreads();
-    float *slab = g.slabs + ((int64_t)(is_value ? 1 : 0) * nwg_trunk + wg_in_trunk) * SLAB;
+    float *slab = g.slabs + (int64_t)blockIdx.x * SLAB;
     for (int e = tid; e < SLAB; e += kThreads) {
         const float *p = lds + e;
         slab[e] = (p[0] + p[SLAB]) + (p[2 * SLAB] + p[3 * SLAB]);
@@ -674,7 +788,27 @@ bool mlp_fused16_fits(const ppo2hip_policy_desc &d, const ppo2hip_rollout &ro, i
     return ro.n > 0 && ro.n * widest * 4 < limit && B * 4 < limit;
 }
 
-int mlp_fused16_grid() { return 256; }   // one 512-thread workgroup per CU (LDS-limited), 128 per trunk
+int mlp_fused16_grid() { return 256; }
+
+// How many of the grid's workgroups run the policy trunk.  A tile costs the value trunk less (a one-output head runs
+// on the vector ALUs, no distribution arithmetic), so an even split leaves its workgroups idle at the end; the split
+// that minimises max(tiles per SIMD x relative cost) over the two trunks is taken instead.
+static int fused16_policy_workgroups(const ppo2hip_policy_desc &d, int64_t B, int grid) {
+    if (const char *e = getenv("PPO2HIP_F16_POLICY_WGS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v < grid) return v;
+    }
+    const int64_t ntiles = (B + 15) / 16;
+    const double cost_value = d.nvalue == 1 ? 0.84 : 0.97;      // relative to a policy tile (measured on gfx950)
+    int best = grid / 2;
+    double best_t = 1e300;
+    for (int wp = grid / 4; wp <= 3 * grid / 4; wp++) {
+        const double tp = (double)ceil_div(ntiles, 4 * (int64_t)wp), tv = (double)ceil_div(ntiles, 4 * (int64_t)(grid - wp)) * cost_value;
+        const double t = tp > tv ? tp : tv;
+        if (t < best_t - 1e-9 || (t < best_t + 1e-9 && abs(wp - grid / 2) < abs(best - grid / 2))) { best_t = t; best = wp; }
+    }
+    return best;
+}   // one 512-thread workgroup per CU (LDS-limited), 128 per trunk
 
 size_t mlp_fused16_workspace_bytes() {
     return align_up((size_t)mlp_fused16_grid() * f16::SLAB * sizeof(float), 256) +
@@ -702,15 +836,26 @@ int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, 
     g.upstream = lc.upstream; g.cliprange = cliprange; g.ent_coef = lc.ent_coef;
     g.vf_coef = lc.upstream ? lc.vf_coef : 1.0f; g.inv_count = (float)inv_count;
     g.slabs = slabs; g.loss_partial = lpart;
-    if (d.ob_dim <= 7) hipLaunchKernelGGL((mlp_fused16_kernel<2, false>), dim3(grid), dim3(kThreads), 0, s, g);
-    else if (d.ob_dim <= 15) hipLaunchKernelGGL((mlp_fused16_kernel<4, false>), dim3(grid), dim3(kThreads), 0, s, g);
-    else if (d.ob_dim <= 19) hipLaunchKernelGGL((mlp_fused16_kernel<5, true>), dim3(grid), dim3(kThreads), 0, s, g);
-    else hipLaunchKernelGGL((mlp_fused16_kernel<8, true>), dim3(grid), dim3(kThreads), 0, s, g);
+    g.nwg_policy = fused16_policy_workgroups(d, B, grid);
+    {   // env = smp / T as a multiplication (smp < 2^31): s = ceil(log2 T), magic = floor(2^32 (2^s - T) / T) + 1
+        const unsigned T = ro.T > 0 ? (unsigned)ro.T : 1u;
+        int sh = 0;
+        while ((1ull << sh) < T) sh++;
+        g.div_magic = (unsigned)((((1ull << sh) - T) << 32) / T + 1);
+        g.div_sh1 = sh < 1 ? sh : 1;
+        g.div_sh2 = sh > 1 ? sh - 1 : 0;
+    }
+    if (d.ob_dim <= 7) hipLaunchKernelGGL((mlp_fused16_kernel<2, false, 0>), dim3(grid), dim3(kThreads), 0, s, g);
+    else if (d.ob_dim <= 15) hipLaunchKernelGGL((mlp_fused16_kernel<4, false, 0>), dim3(grid), dim3(kThreads), 0, s, g);
+    else if (d.ob_dim == 16) hipLaunchKernelGGL((mlp_fused16_kernel<5, false, 1>), dim3(grid), dim3(kThreads), 0, s, g);
+    else if (d.ob_dim == 17) hipLaunchKernelGGL((mlp_fused16_kernel<5, false, 2>), dim3(grid), dim3(kThreads), 0, s, g);
+    else if (d.ob_dim <= 19) hipLaunchKernelGGL((mlp_fused16_kernel<5, true, 0>), dim3(grid), dim3(kThreads), 0, s, g);
+    else hipLaunchKernelGGL((mlp_fused16_kernel<8, true, 0>), dim3(grid), dim3(kThreads), 0, s, g);
     int rc = check_launch("mlp_fused16_kernel");
     if (rc) return rc;
     FusedImage im;
     im.slab_elems = SLAB; im.s_w1 = S_W1; im.s_w2 = S_W2; im.s_wh = S_WH; im.s_bh = S_BH; im.head_cols = 16; im.s_logstd = S_BH + 8;
-    return fused_finalize(im, slabs, grid / 2, lpart, grid, d, fo, inv_count, grads, losses, s);
+    return fused_finalize(im, slabs, g.nwg_policy, grid - g.nwg_policy, lpart, grid, d, fo, inv_count, grads, losses, s);
 }
 
 }  // namespace ppo2hip
