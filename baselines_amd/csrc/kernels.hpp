@@ -104,10 +104,21 @@ struct FusedImage {
     int s_w1, s_w2, s_wh, s_bh, head_cols;
     int s_logstd;   // where the image holds the summed logstd gradient, or -1: it is in the loss partial rows
 };
+// Optimiser step folded into the finalize launch (single process, small arenas): every block that has summed its 64
+// gradient elements meets the others at a grid barrier over the per-block sums of squares and then applies
+// clip + Adam to those same elements, so a minibatch costs two launches instead of three.
+struct AdamFuse {
+    float *theta, *m, *v;
+    float a, beta1, beta2, omb1, omb2, eps, gscale, max_norm;
+    float *header;            // adam scratch header: [0] global norm, [1] applied scale
+    double *partial;          // [blocks] per-block sums of squares          (workspace of the fused gradient kernel)
+    unsigned *barrier;        // [2] arrival counter (zeroed by the gradient kernel of the same minibatch), fault flag
+};
+size_t fused_adam_extra_bytes();
 // slabs: nslabs_policy gradient images of the policy trunk, then nslabs_value of the value trunk
 int fused_finalize(const FusedImage &im, const float *slabs, int nslabs_policy, int nslabs_value, const double *lpart, int nloss_rows,
                    const ppo2hip_policy_desc &d, const FusedOffsets &fo, double inv_count, float *grads, float *losses,
-                   hipStream_t s);
+                   hipStream_t s, const AdamFuse *adam = nullptr);
 bool mlp_fused16_supported(const ppo2hip_policy_desc &d);
 // every rollout array and the index list stay under 4 GB (the kernel addresses them with 32-bit byte offsets)
 bool mlp_fused16_fits(const ppo2hip_policy_desc &d, const ppo2hip_rollout &ro, int64_t B);
@@ -115,7 +126,7 @@ size_t mlp_fused16_workspace_bytes();
 int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params,
                      const FusedOffsets &fo, const ppo2hip_rollout &ro, const int32_t *idx, int64_t B,
                      const double *stats, float cliprange, double inv_count, float *grads, float *losses, void *ws,
-                     size_t ws_bytes, hipStream_t s);
+                     size_t ws_bytes, hipStream_t s, AdamFuse *adam = nullptr);
 bool mlp_fused_supported(const ppo2hip_policy_desc &d);
 size_t mlp_fused_workspace_bytes();
 int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params,

@@ -542,9 +542,18 @@ struct FinalizeArgs {
     float *losses, *dlogstd;
 };
 
+constexpr int kFusedAdamMaxBlocks = 256;      // one per CU: resident together whatever else the chip is doing
+size_t fused_adam_extra_bytes() { return 256 + kFusedAdamMaxBlocks * sizeof(double); }
+
 constexpr int kFinGroups = 16;   // slab groups per block: 1024 threads, every lane a handful of independent loads
 
-__global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(FinalizeArgs f) {
+// ADAM: the blocks that sum gradient elements then take the optimiser step on those same elements.  The global norm
+// needs every block's sum of squares: each stores its own with an agent-scope store, arrives on a counter and waits
+// until all have (all blocks of this launch are resident at once: at most 2 x 1024 threads of them per CU are asked
+// for, far fewer than the chip holds); the wait is bounded, and a block that gives up raises the fault flag instead of
+// spinning on.  The parameters, m and v of a block's elements are loaded before the wait.
+template <bool ADAM>
+__global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(FinalizeArgs f, AdamFuse ad) {
     __shared__ float part[kFinGroups][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int b = blockIdx.x;
@@ -588,16 +597,63 @@ __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(Finaliz
                 out = f.dlogstd + (e - na);
             }
         }
+        float th = 0.f, mi = 0.f, vi = 0.f;
+        int64_t pidx = -1;
+        if (ADAM && grp == 0 && out) {
+            pidx = out - f.grads;
+            th = ad.theta[pidx]; mi = ad.m[pidx]; vi = ad.v[pidx];
+        }
         float s = 0.f;
         if (p)
             for (int z = grp; z < nz; z += kFinGroups) s += p[(int64_t)z * f.slab_elems];
         part[grp][lane] = s;
         __syncthreads();
+        float t = 0.f;
         if (grp == 0 && out) {
-            float t = 0.f;
 #pragma unroll
             for (int q = 0; q < kFinGroups; q++) t += part[q][lane];
             *out = t;
+        }
+        if (ADAM && grp == 0) {           // wave 0 of every gradient block
+            const int nb = f.nseg_blocks + f.nhead_blocks;
+            float scale = ad.gscale;
+            if (ad.max_norm > 0.f) {
+                const double x = (double)(t * ad.gscale);
+                const double mine = wave_sum(x * x);
+                if (lane == 0) {
+                    // the sum goes out as a write-through (agent-scope) store and is drained before the arrival is counted;
+                    // the poll and the reads of the other blocks' sums below are agent-scope loads: no cache write-back or
+                    // invalidate is needed on either side
+                    __hip_atomic_store(&ad.partial[b], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(&ad.barrier[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int spins = 0;
+                    while (__hip_atomic_load(&ad.barrier[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nb) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1 << 22)) {      // never expected; leave rather than hang the device
+                            __hip_atomic_store(&ad.barrier[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // every block sums the same values in the same order, so all of them apply the same scale
+                double ss = 0.0;
+                for (int q = lane; q < nb; q += 64) ss += __hip_atomic_load(&ad.partial[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ss = wave_sum(ss);
+                const float norm = (float)sqrt(ss);
+                scale = ad.gscale * (ad.max_norm / fmaxf(norm, ad.max_norm));
+                if (b == 0 && lane == 0) ad.header[0] = norm;
+            }
+            if (b == 0 && lane == 0) ad.header[1] = scale;
+            if (pidx >= 0) {
+                const float gs = t * scale;
+                const float m1 = ad.beta1 * mi + ad.omb1 * gs;
+                const float v1 = ad.beta2 * vi + ad.omb2 * (gs * gs);
+                ad.m[pidx] = m1;
+                ad.v[pidx] = v1;
+                ad.theta[pidx] = th + (-ad.a) * m1 / (sqrtf(v1) + ad.eps);
+            }
         }
     } else {
         // loss scalars (+ the logstd gradient when it travels in the loss partial rows): one wave per output
@@ -617,7 +673,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(Finaliz
 
 int fused_finalize(const FusedImage &im, const float *slabs, int nslabs_policy, int nslabs_value, const double *lpart, int nloss_rows,
                    const ppo2hip_policy_desc &d, const FusedOffsets &fo, double inv_count, float *grads, float *losses,
-                   hipStream_t s) {
+                   hipStream_t s, const AdamFuse *adam) {
     const int H1 = d.hidden1, H2 = d.hidden2, D = d.ob_dim, A = d.ac_dim, R = d.nvalue;
     FinalizeArgs fa;
     fa.t.n = 0;
@@ -640,7 +696,15 @@ int fused_finalize(const FusedImage &im, const float *slabs, int nslabs_policy, 
     fa.a_dst = fo.a_wh; fa.v_dst = fo.v_wh;
     fa.grads = grads; fa.loss_partial = lpart; fa.nloss_rows = nloss_rows; fa.A_gaussian = gauss ? A : 0;
     fa.inv_count = inv_count; fa.losses = losses; fa.dlogstd = gauss ? grads + fo.logstd : nullptr;
-    hipLaunchKernelGGL(fused_finalize_kernel, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(64 * kFinGroups), 0, s, fa);
+    if (adam) {
+        if (fa.nseg_blocks + fa.nhead_blocks > kFusedAdamMaxBlocks || (gauss && im.s_logstd < 0)) {
+            set_error("fused_finalize: optimiser step cannot be folded in for this shape");
+            return PPO2HIP_EUNSUPPORTED;
+        }
+        hipLaunchKernelGGL(fused_finalize_kernel<true>, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(64 * kFinGroups), 0, s, fa, *adam);
+    } else {
+        hipLaunchKernelGGL(fused_finalize_kernel<false>, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(64 * kFinGroups), 0, s, fa, AdamFuse{});
+    }
     return check_launch("fused_finalize_kernel");
 }
 

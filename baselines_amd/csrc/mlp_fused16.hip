@@ -86,6 +86,7 @@ struct Fused16Args {
     unsigned div_magic;      // smp / T = (t + ((smp - t) >> div_sh1)) >> div_sh2 with t = mulhi(div_magic, smp)
     int div_sh1, div_sh2;
     int nwg_policy;          // workgroups 0 .. nwg_policy-1 run the policy trunk, the rest the value trunk
+    unsigned *fin_barrier;   // arrival counter and fault flag of the finalize launch that follows: zeroed here
     float *slabs;            // [workgroup][SLAB]: the policy trunk's images, then the value trunk's
     double *loss_partial;    // [gridDim.x][kLossStride]
 };
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
+    if (blockIdx.x == 0 && threadIdx.x < 2) g.fin_barrier[threadIdx.x] = 0u;
     const bool is_value = (int)blockIdx.x >= g.nwg_policy;
     const int nwg_trunk = is_value ? (int)gridDim.x - g.nwg_policy : g.nwg_policy;
     const int wg_in_trunk = is_value ? (int)blockIdx.x - g.nwg_policy : (int)blockIdx.x;
@@ -812,13 +814,13 @@ static int fused16_policy_workgroups(const ppo2hip_policy_desc &d, int64_t B, in
 
 size_t mlp_fused16_workspace_bytes() {
     return align_up((size_t)mlp_fused16_grid() * f16::SLAB * sizeof(float), 256) +
-           align_up((size_t)mlp_fused16_grid() * f16::kLossStride * sizeof(double), 256);
+           align_up((size_t)mlp_fused16_grid() * f16::kLossStride * sizeof(double), 256) + fused_adam_extra_bytes();
 }
 
 int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params,
                      const FusedOffsets &fo, const ppo2hip_rollout &ro, const int32_t *idx, int64_t B,
                      const double *stats, float cliprange, double inv_count, float *grads, float *losses, void *ws,
-                     size_t ws_bytes, hipStream_t s) {
+                     size_t ws_bytes, hipStream_t s, AdamFuse *adam) {
     using namespace f16;
     if (ws_bytes < mlp_fused16_workspace_bytes()) {
         set_error("mlp_fused16_grad: workspace too small");
@@ -827,7 +829,13 @@ int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, 
     const int grid = mlp_fused16_grid();
     float *slabs = (float *)ws;
     double *lpart = (double *)((char *)ws + align_up((size_t)grid * SLAB * sizeof(float), 256));
+    char *extra = (char *)lpart + align_up((size_t)grid * kLossStride * sizeof(double), 256);
+    if (adam) {
+        adam->barrier = (unsigned *)extra;
+        adam->partial = (double *)(extra + 256);
+    }
     Fused16Args g;
+    g.fin_barrier = (unsigned *)extra;
     g.obs = (const float *)ro.obs; g.actions = ro.actions; g.returns = ro.returns; g.values = ro.values;
     g.neglogpacs = ro.neglogpacs; g.advs = ro.advs; g.adv_f64 = ro.adv_f64; g.T = ro.T; g.E = ro.E; g.n = ro.n;
     g.idx = idx; g.B = B; g.stats = stats; g.params = params;
@@ -855,7 +863,7 @@ int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, 
     if (rc) return rc;
     FusedImage im;
     im.slab_elems = SLAB; im.s_w1 = S_W1; im.s_w2 = S_W2; im.s_wh = S_WH; im.s_bh = S_BH; im.head_cols = 16; im.s_logstd = S_BH + 8;
-    return fused_finalize(im, slabs, g.nwg_policy, grid - g.nwg_policy, lpart, grid, d, fo, inv_count, grads, losses, s);
+    return fused_finalize(im, slabs, g.nwg_policy, grid - g.nwg_policy, lpart, grid, d, fo, inv_count, grads, losses, s, adam);
 }
 
 }  // namespace ppo2hip

@@ -205,7 +205,8 @@ static int mlp_path_choice(const ppo2hip_policy_desc &d, const ppo2hip_rollout &
 
 static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const Layout &L, const float *p,
                     const ppo2hip_rollout &ro, const int32_t *idx, int64_t B, const double *stats, float cliprange,
-                    double inv_count, float *grads, float *losses, void *ws, size_t ws_bytes, hipStream_t s) {
+                    double inv_count, float *grads, float *losses, void *ws, size_t ws_bytes, hipStream_t s,
+                    AdamFuse *adam = nullptr, bool *adam_done = nullptr) {
     Carver c(ws, ws_bytes);
     MlpBuf w;
     carve_mlp(d, B, c, w, true);
@@ -219,9 +220,13 @@ static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
     if (path) {
         FusedOffsets fo{L.off("pi_fc1/w"), L.off("pi_fc2/w"), L.off("pi/w"), L.off("vf_fc1/w"), L.off("vf_fc2/w"),
                         L.off("vf/w"), gauss ? L.off("logstd") : 0};
-        if (path == 16)
+        if (path == 16) {
+            // the optimiser step rides in the finalize launch when the caller offers it and the arena is small enough
+            const bool fold = adam && L.total <= 16384 && !(getenv("PPO2HIP_NO_FUSED_ADAM"));
+            if (fold && adam_done) *adam_done = true;
             return mlp_fused16_grad(d, lc, p, fo, ro, idx, B, stats, cliprange, inv_count, grads, losses, w.fused,
-                                    w.fused_bytes, s);
+                                    w.fused_bytes, s, fold ? adam : nullptr);
+        }
         return mlp_fused_grad(d, lc, p, fo, ro, idx, B, stats, cliprange, inv_count, grads, losses, w.fused,
                               w.fused_bytes, s);
     }
@@ -703,11 +708,11 @@ extern "C" int ppo2hip_act_step(const ppo2hip_policy_desc *desc, const float *pa
     return ppo2hip_sample_actions(desc, params, pi, B, seed, step, deterministic, actions, neglogp, nullptr, stream);
 }
 
-extern "C" int ppo2hip_ppo_grad(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss, const float *params,
-                                const ppo2hip_rollout *rollout, const int32_t *idx, int64_t B,
-                                const int32_t *mb_envs, int32_t nsteps_mb, const double *stats, float cliprange,
-                                double inv_count, float *grads, float *losses, void *workspace,
-                                size_t workspace_bytes, void *stream) {
+static int ppo_grad_impl(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss, const float *params,
+                         const ppo2hip_rollout *rollout, const int32_t *idx, int64_t B,
+                         const int32_t *mb_envs, int32_t nsteps_mb, const double *stats, float cliprange,
+                         double inv_count, float *grads, float *losses, void *workspace,
+                         size_t workspace_bytes, void *stream, AdamFuse *adam, bool *adam_done) {
     PPO2HIP_REQUIRE(desc && loss && params && rollout && grads && losses && workspace && B >= 1,
                     "ppo_grad: bad argument");
     PPO2HIP_REQUIRE(rollout->obs && rollout->actions && rollout->returns && rollout->values &&
@@ -723,12 +728,21 @@ extern "C" int ppo2hip_ppo_grad(const ppo2hip_policy_desc *desc, const ppo2hip_l
     hipStream_t s = (hipStream_t)stream;
     if (desc->kind == PPO2HIP_POLICY_MLP)
         return mlp_grad(*desc, *loss, L, params, *rollout, idx, B, stats, cliprange, inv_count, grads, losses,
-                        workspace, workspace_bytes, s);
+                        workspace, workspace_bytes, s, adam, adam_done);
     if (cnn_kind(*desc))
         return cnn_grad(*desc, *loss, L, params, *rollout, idx, B, mb_envs, nsteps_mb, stats, cliprange, inv_count, grads,
                         losses, workspace, workspace_bytes, s);
     set_error("ppo_grad: unknown policy kind %d", desc->kind);
     return PPO2HIP_EUNSUPPORTED;
+}
+
+extern "C" int ppo2hip_ppo_grad(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss, const float *params,
+                                const ppo2hip_rollout *rollout, const int32_t *idx, int64_t B,
+                                const int32_t *mb_envs, int32_t nsteps_mb, const double *stats, float cliprange,
+                                double inv_count, float *grads, float *losses, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    return ppo_grad_impl(desc, loss, params, rollout, idx, B, mb_envs, nsteps_mb, stats, cliprange, inv_count, grads, losses,
+                         workspace, workspace_bytes, stream, nullptr, nullptr);
 }
 
 extern "C" int ppo2hip_ppo_epoch(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss, float *params,
@@ -746,11 +760,20 @@ extern "C" int ppo2hip_ppo_epoch(const ppo2hip_policy_desc *desc, const ppo2hip_
     const int64_t P = ppo2hip_param_count(desc);
     if (P < 0) return PPO2HIP_EINVAL;
     for (int64_t j = 0; j < nmb; j++) {
-        int rc = ppo2hip_ppo_grad(desc, loss, params, rollout, idx + j * nbatch_train, nbatch_train, nullptr, 0,
-                                  stats ? stats + 3 * j : nullptr, cliprange, 1.0 / (double)nbatch_train, grads,
-                                  losses + 8 * j, workspace, workspace_bytes, stream);
+        // where the gradient route can, the optimiser step of the minibatch rides in its last launch
+        const int64_t t = t_first + j;
+        AdamFuse af{};
+        af.theta = params; af.m = adam_m; af.v = adam_v;
+        af.a = (float)(lr * sqrt(1.0 - pow(beta2, (double)t)) / (1.0 - pow(beta1, (double)t)));
+        af.beta1 = (float)beta1; af.beta2 = (float)beta2; af.omb1 = (float)(1.0 - beta1); af.omb2 = (float)(1.0 - beta2);
+        af.eps = (float)epsilon; af.gscale = 1.f; af.max_norm = (float)max_grad_norm; af.header = (float *)adam_scratch;
+        bool folded = false;
+        int rc = ppo_grad_impl(desc, loss, params, rollout, idx + j * nbatch_train, nbatch_train, nullptr, 0,
+                               stats ? stats + 3 * j : nullptr, cliprange, 1.0 / (double)nbatch_train, grads,
+                               losses + 8 * j, workspace, workspace_bytes, stream, t >= 1 ? &af : nullptr, &folded);
         if (rc) return rc;
-        rc = ppo2hip_adam_step(params, grads, adam_m, adam_v, P, lr, t_first + j, beta1, beta2, epsilon, 1.0,
+        if (folded) continue;
+        rc = ppo2hip_adam_step(params, grads, adam_m, adam_v, P, lr, t, beta1, beta2, epsilon, 1.0,
                                max_grad_norm, adam_scratch, stream);
         if (rc) return rc;
     }

@@ -62,7 +62,7 @@ def dense_flops_per_sample(D, hidden, A, R):
 def measured_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate
     rocprofv3 runs of this script), or None when no profile of this workload is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_d_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
     try:
         with open(path) as fh:
             prof = json.load(fh)
@@ -187,8 +187,28 @@ def cpu_baseline(model, ro, cfg, budget_s=20.0):
     for _ in range(reps):
         one_update()
     dt = (time.perf_counter() - t0) / reps
-    return dict(value=N / dt, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d full updates of the same workload (N=%d, %d minibatches x %d epochs), float32 torch-CPU + NumPy"
+    cores = torch.get_num_threads()
+    # the same update on ONE thread (bounded: one update, skipped when the multi-thread figure says it would take minutes)
+    one_thread = None
+    if dt * cores < 90.0:
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
+        one_update()
+        one_thread = N / (time.perf_counter() - t0)
+        torch.set_num_threads(cores)
+    model_name = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model_name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(value=N / dt, unit="samples/s", cores=cores, kind="port", cpu_model=model_name,
+                value_one_thread=one_thread,
+                sample="%d full updates of the same workload (N=%d, %d minibatches x %d epochs), float32 torch-CPU + NumPy; "
+                       "value_one_thread: one such update with torch.set_num_threads(1)"
                        % (reps, N, cfg["nmb"], cfg["noptepochs"]))
 
 
@@ -286,11 +306,15 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         last = step()
+        marks[k + 1].record()            # GPU-side step boundaries: the spread of the per-step times, beside the wall mean
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
@@ -334,31 +358,41 @@ def main():
     # the same kernel family on a rollout large enough to be bandwidth- rather than latency-bound: the 65536-env x
     # 128-step rollout of the env-sharded configuration, whole, on this one GPU (R = 1)
     def gae_large():
-        Tl, El = 128, 65536
+        Tl, El, nsets = 128, 65536, 4
         gen = torch.Generator(device=device)
         gen.manual_seed(3)
-        rw = torch.randn(Tl, El, 1, generator=gen, device=device)
-        vl = torch.randn(Tl, El, 1, generator=gen, device=device)
-        dn = (torch.rand(Tl, El, generator=gen, device=device) < 0.005).to(torch.uint8)
-        lv = torch.randn(El, 1, generator=gen, device=device)
-        ld = torch.zeros(El, dtype=torch.uint8, device=device)
-        o = [torch.empty_like(rw) for _ in range(3)]
         g1 = (ctypes.c_double * 1)(0.99)
-        call = lambda: check(lib.ppo2hip_gae_f32(ptr(rw), ptr(vl), ptr(dn), ptr(lv), ptr(ld), g1, 0.95, Tl, El, 1, ptr(o[0]),
-                                                 ptr(o[1]), ptr(o[2]), stream), "gae")
-        call()
+        # four distinct sets of inputs and outputs (176 MB each, 704 MB in all) visited in turn, so that no launch finds
+        # its operands in the 256 MB Infinity Cache left there by the launch before it
+        sets = []
+        for _ in range(nsets):
+            rw = torch.randn(Tl, El, 1, generator=gen, device=device)
+            vl = torch.randn(Tl, El, 1, generator=gen, device=device)
+            dn = (torch.rand(Tl, El, generator=gen, device=device) < 0.005).to(torch.uint8)
+            lv = torch.randn(El, 1, generator=gen, device=device)
+            ld = torch.zeros(El, dtype=torch.uint8, device=device)
+            sets.append((rw, vl, dn, lv, ld, [torch.empty_like(rw) for _ in range(3)]))
+
+        def call(k):
+            rw, vl, dn, lv, ld, o = sets[k % nsets]
+            check(lib.ppo2hip_gae_f32(ptr(rw), ptr(vl), ptr(dn), ptr(lv), ptr(ld), g1, 0.95, Tl, El, 1, ptr(o[0]), ptr(o[1]),
+                                      ptr(o[2]), stream), "gae")
+        for k in range(nsets):
+            call(k)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.empty(64 << 20, device=device).normal_()
         a.record()
-        for _ in range(reps):
-            call()
+        for k in range(reps):
+            call(k)
         b.record()
         torch.cuda.synchronize()
         ms = a.elapsed_time(b) / reps
-        nbytes = Tl * El * 17 + El * 5
+        nbytes = Tl * El * 21 + El * 5           # 17 B/sample of the scan itself + the third output (advs_ori, 4 B/sample)
         return {"bound": "hbm", "kernel": "gae_kernel<8>", "workload": "65536 envs x 128 steps, R=1 (configs[3], whole, on one GPU)",
                 "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": nbytes, "ms_per_launch": ms}
+                "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": nbytes, "ms_per_launch": ms,
+                "buffer_sets": nsets, "note": "bytes include the third output array; %d buffer sets of 176 MB rotate so the "
+                                              "256 MB Infinity Cache holds none of a launch's operands" % nsets}
     gae_large_roofline = gae_large() if rank == 0 else None
     # median over the minibatches: the first evaluation of an epoch can sit behind the index upload, which is not
     # launch time
@@ -399,6 +433,7 @@ def main():
         out = {
             "metric": "PPO2 samples/sec (GAE+update)", "value": world * N * args.steps / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_gpu_events": {"median": step_ms[len(step_ms) // 2], "min": step_ms[0], "max": step_ms[-1]},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s synthetic %s nenvs=%d nsteps=%d per GPU, %d minibatches x %d epochs, %s loss"
                                    % (which, shape, E, T, cfg["nmb"], cfg["noptepochs"], "upstream" if cfg["upstream"] else "fork"),
@@ -410,14 +445,15 @@ def main():
                                    "ppo_grad = gather + layered fp32-MFMA GEMM / implicit-GEMM conv launches + loss + slab reductions",
                          "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / MFMA_F32_PEAK_TFLOPS,
-                         "traffic": measured_traffic(args.workload, "ppo2hip::mlp_fused16_kernel<5, true>") if fused else None,
+                         "traffic": measured_traffic(args.workload, "ppo2hip::mlp_fused16_kernel<5, false, 2>") if fused else None,
                          "flops_per_launch": flops_mb, "ms_per_launch": grad_ms},
             "gae_roofline": {"bound": "hbm", "kernel": "gae_tiled_kernel", "achieved": gae_gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": gae_gbs / HBM_PEAK_GBS, "bytes_per_launch": gae_bytes,
                              "traffic": measured_traffic(args.workload, "ppo2hip::gae_tiled_kernel"),
                              "ms_per_launch": gae_ms},
             "gae_roofline_large": gae_large_roofline,
-            "device_measured": {"copy_gbs": copy_gbs, "library_sgemm_tflops": sgemm_tf,
+            "device_measured": {"copy_gbs": copy_gbs, "gae_large_vs_copy": (gae_large_roofline["achieved"] / copy_gbs) if gae_large_roofline else None,
+                                "library_sgemm_tflops": sgemm_tf,
                                 "note": "1 GiB device-to-device copy (read + write) and an 8192^3 fp32 torch.matmul on this card"},
             "losses": [float(x) for x in losses],
         }
