@@ -462,8 +462,15 @@ struct TransposedOnes {  // as Transposed, plus a row `ones_row` of 1.0 (folds t
 };
 
 // ---- epilogues -------------------------------------------------------------------------
+// tanh x = 1 - 2 / (2^(2 log2(e) x) + 1) on the hardware exp2 / rcp (1 ulp each): |error| <= ~1.5e-7 absolute, five
+// vector instructions where libm's tanhf takes about forty — with the fp32 matrix products running on the same vector
+// ALUs, a 64-wide epilogue of tanhf calls cost a K = 256 product 40 % on top of its multiply time.
+__device__ inline float fast_tanh(float x) {
+    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
 __device__ inline float apply_act(float x, int act) {
-    if (act == 1) return tanhf(x);
+    if (act == 1) return fast_tanh(x);
     if (act == 2) return x > 0.f ? x : 0.f;
     return x;
 }

@@ -127,6 +127,22 @@ int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, 
                      const FusedOffsets &fo, const ppo2hip_rollout &ro, const int32_t *idx, int64_t B,
                      const double *stats, float cliprange, double inv_count, float *grads, float *losses, void *ws,
                      size_t ws_bytes, hipStream_t s, AdamFuse *adam = nullptr);
+// ---- fused forward / loss / input-gradient chain of the 256-128 two-trunk MLP (mlp_fused256.hip) ---------------
+struct Fused256Buffers {
+    const float *X;                           // gathered minibatch rows (gather_minibatch)
+    const void *ACT;
+    const float *RET, *OLDV, *NLP, *ADV;
+    float *H1[2], *H2[2], *DZ1[2], *DZ2[2], *DOUT[2];      // per trunk (policy, value)
+    double *loss_partial;                     // mlp_fused256_loss_bytes()
+};
+bool mlp_fused256_supported(const ppo2hip_policy_desc &d);
+size_t mlp_fused256_loss_bytes();
+int mlp_fused256_chain(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params, const FusedOffsets &fo,
+                       const Fused256Buffers &b, int64_t B, float cliprange, double inv_count, float *losses, float *dlogstd,
+                       hipStream_t s);
+// loss scalars (and the logstd gradient riding at 8 + o) from per-workgroup partial rows of 8 + 64 doubles
+int fused_loss_finalize(const double *lpart, int nrows, int A_gaussian, double inv_count, float *losses, float *dlogstd,
+                        hipStream_t s);
 bool mlp_fused_supported(const ppo2hip_policy_desc &d);
 size_t mlp_fused_workspace_bytes();
 int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params,

@@ -55,11 +55,6 @@ struct FusedArgs {
 
 __device__ inline int rho(int r) { return (r & 3) + 8 * (r >> 2); }
 
-// |error| <= ~1e-7 absolute over the whole range (v_exp_f32 / v_rcp_f32 are 1 ulp)
-__device__ inline float fast_tanh(float x) {
-    const float t = __expf(2.0f * x);
-    return 1.0f - 2.0f * __frcp_rn(t + 1.0f);
-}
 
 template <int H1B, int H2B>
 struct FusedLayout {
@@ -706,6 +701,17 @@ int fused_finalize(const FusedImage &im, const float *slabs, int nslabs_policy, 
         hipLaunchKernelGGL(fused_finalize_kernel<false>, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(64 * kFinGroups), 0, s, fa, AdamFuse{});
     }
     return check_launch("fused_finalize_kernel");
+}
+
+int fused_loss_finalize(const double *lpart, int nrows, int A_gaussian, double inv_count, float *losses, float *dlogstd,
+                        hipStream_t s) {
+    FinalizeArgs fa{};
+    fa.t.n = 0; fa.nseg_blocks = 0; fa.nhead_blocks = 0;
+    fa.s_logstd = -1;                       // the logstd gradient travels in the partial rows
+    fa.loss_partial = lpart; fa.nloss_rows = nrows; fa.A_gaussian = A_gaussian; fa.inv_count = inv_count;
+    fa.losses = losses; fa.dlogstd = A_gaussian ? dlogstd : nullptr;
+    hipLaunchKernelGGL(fused_finalize_kernel<false>, dim3(1), dim3(64 * kFinGroups), 0, s, fa, AdamFuse{});
+    return check_launch("fused_finalize_kernel (losses)");
 }
 
 bool mlp_fused_supported(const ppo2hip_policy_desc &d) {

@@ -1,0 +1,418 @@
+// Forward, loss and input-gradient chain of the fork's own network — two separate 256-128 tanh trunks, R value
+// channels (baselines/ppo2/policies.py:139-151 under the loss of baselines/ppo2/common_functions.py:26-54) — in ONE
+// launch on 16-sample tiles, for minibatch rows that gather_minibatch has laid out contiguously.
+//
+// What is fused and what is not.  A trunk's 256 x 128 weight-gradient accumulator is 32768 floats: it fits no wave's
+// registers, so the three weight-gradient products stay on the GEMM (fc_wgrad_slabs), fed by what this kernel
+// writes: h1, h2, d(loss)/d(head), dz2, dz1.  Everything else — layer 1, layer 2, head, distribution and loss
+// arithmetic, and the two input-gradient products — happens between one read of a sample's row and those writes,
+// with the activations in registers: per sample and trunk 1.6 KB are written and later read once, where the
+// layer-by-layer route moves 5.2 KB through HBM in 13 launches.
+//
+// Mapping (v_mfma_f32_16x16x4_f32; lane l: li = l & 15 the sample, lk = l >> 4):
+//   operands A[i = li][k = lk], B[k = lk][j = li]; result D[row = 4 lk + r][col = li].
+//   Units sit on rows, samples on columns, so a layer's accumulator (register r of block m = unit 16 m + 4 lk + r) is
+//   the B operand of the next product as it stands; the A operand of that k-step is the weight row of that unit.
+// W2 is held ONCE in LDS (128 KB), row-major [in][out] with the out index XOR-ed by
+//   f(in) = (in & 15) | (((in ^ (in >> 2)) & 1) << 4),
+// which makes both its uses free of bank conflicts within a half-wave: the forward product reads a row `in` per lane
+// quarter with lanes along out, the backward product a column segment per lane quarter with lanes along in.
+#include "gemm_core.hpp"
+#include "kernels.hpp"
+
+namespace ppo2hip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+namespace f256 {
+constexpr int kThreads = 512, kWaves = 8;
+constexpr int H1 = 256, H2 = 128, HB1 = H1 / 16, HB2 = H2 / 16;
+constexpr int KQ = 5;                          // layer-1 k-steps: ob_dim + 1 <= 20
+constexpr int W2S = 0;                         // [256 in][128 out ^ f(in)]
+constexpr int W1LD = H1 + 16;                  // row stride of W1S: the four lane quarters of a read fall on distinct banks
+constexpr int W1S = W2S + H1 * H2;             // [20 rows][W1LD]: rows 0..D-1 weights, row D bias, rest zero
+constexpr int WHS = W1S + 4 * KQ * W1LD;       // [128 units][16 outputs]
+constexpr int B2S = WHS + H2 * 16;             // [128]
+constexpr int BHS = B2S + H2;                  // [16]
+constexpr int TOTAL = BHS + 16;
+static_assert(TOTAL * 4 + 1024 <= 160 * 1024, "LDS budget");
+constexpr int kLossStride = 8 + 64;            // the partial-row format of the loss block of fused_finalize_kernel
+}  // namespace f256
+
+struct Fused256Args {
+    const float *X;          // [B, D] gathered observations
+    const void *ACT;         // [B, A] float (Gaussian) or [B] int32 (Categorical)
+    const float *RET, *OLDV, *NLP, *ADV;     // [B, R], [B, R], [B], [B] (advantages already normalised)
+    int64_t B;
+    const float *params;
+    int64_t a_w1, a_w2, a_wh, v_w1, v_w2, v_wh, logstd_off;
+    int D, A, R, dist, upstream;
+    float cliprange, ent_coef, vf_coef, inv_count;
+    float *H1[2], *H2[2], *DZ1[2], *DZ2[2], *DOUT[2];    // per trunk (0 policy, 1 value): [B,256] [B,128] [B,256] [B,128] [B,O]
+    double *loss_partial;    // [gridDim.x][kLossStride]
+};
+
+__global__ __launch_bounds__(f256::kThreads, 2) void mlp_fused256_kernel(Fused256Args g) {
+    using namespace f256;
+    __shared__ __attribute__((aligned(16))) float lds[TOTAL];
+    __shared__ double red[kWaves * 24];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int trunk = blockIdx.x & 1;
+    const bool is_value = trunk != 0;
+    const int nwg_trunk = gridDim.x >> 1, wg_in_trunk = blockIdx.x >> 1;
+    const int64_t o_w1 = is_value ? g.v_w1 : g.a_w1, o_w2 = is_value ? g.v_w2 : g.a_w2, o_wh = is_value ? g.v_wh : g.a_wh;
+    const int D = g.D, O = is_value ? g.R : g.A;
+    const bool gaussian = g.dist == PPO2HIP_DIST_GAUSSIAN;
+    const float *P = g.params;
+
+    // ---- stage the trunk's weights ---------------------------------------------------------------------------
+    for (int e = tid; e < H1 * H2; e += kThreads) {
+        const int in = e >> 7, out = e & 127;
+        const int f = (in & 15) | (((in ^ (in >> 2)) & 1) << 4);
+        lds[W2S + in * H2 + (out ^ f)] = P[o_w2 + e];
+    }
+    for (int e = tid; e < 4 * KQ * H1; e += kThreads) {
+        const int k = e >> 8;
+        lds[W1S + k * W1LD + (e & 255)] = k <= D ? P[o_w1 + e] : 0.f;      // (w, b) are adjacent in the arena: row D is the bias
+    }
+    for (int e = tid; e < H2 * 16; e += kThreads) {
+        const int u = e >> 4, o = e & 15;
+        lds[WHS + e] = o < O ? P[o_wh + (int64_t)u * O + o] : 0.f;
+    }
+    if (tid < H2) lds[B2S + tid] = P[o_w2 + (int64_t)H1 * H2 + tid];
+    if (tid < 16) lds[BHS + tid] = tid < O ? P[o_wh + (int64_t)H2 * O + tid] : 0.f;
+    __syncthreads();
+
+    // Lane-constant byte addresses of the operand reads; every read below is one of these plus a compile-time offset
+    // that fits the 16-bit offset field of ds_read (the bases are made opaque once per tile, or the compiler hoists
+    // one address register per read out of the tile loop and spills them).
+    //   W2 forward, k-step (mb, r): in = 16 mb + 4 lk + r, out = 16 m + li -> in*128 + 32 (m >> 1) + ((li ^ f) ^ (m & 1 ? 16 : 0))
+    //   W2 backward, k-step (m, r): in = 16 mb + li, out = 16 m + 4 lk + r -> same form with the roles exchanged
+    int a_fw[4], a_bw[4];
+    {
+        const int F = li | (((li ^ (li >> 2)) & 1) << 4);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int inl = 4 * lk + r;
+            const int f = inl | (((r ^ lk) & 1) << 4);
+            a_fw[r] = 4 * (W2S + inl * H2 + (li ^ f));
+            a_bw[r] = 4 * (W2S + li * H2 + ((4 * lk + r) ^ F));
+        }
+    }
+    int a_l1 = 4 * (W1S + lk * W1LD + li);         // + 4 (4 q W1LD + 16 mb)
+    int a_hf = 4 * (WHS + lk * 64 + li);           // + 4 (256 m + 16 r): unit 16 m + 4 lk + r, output li
+    int a_hb = 4 * (WHS + li * 16 + 4 * lk);       // + 4 (256 m): unit 16 m + li, outputs 4 lk .. 4 lk + 3
+    int a_b = 16 * lk;                             // + 4 (B2S + 16 m) or + 4 BHS
+    const char *const ldsb = (const char *)lds;
+    auto ldf = [ldsb](int base, int off) { return *(const float *)(ldsb + base + off); };
+    auto ldf4 = [ldsb](int base, int off) { return *(const f32x4 *)(ldsb + base + off); };
+
+    float inv_std[4] = {0.f, 0.f, 0.f, 0.f};
+    float sum_logstd = 0.f;
+    if (!is_value && gaussian) {
+        for (int k = 0; k < g.A; k++) sum_logstd += P[g.logstd_off + k];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (4 * lk + r < g.A) inv_std[r] = expf(-P[g.logstd_off + 4 * lk + r]);
+    }
+    const float sc = g.inv_count / (float)g.R, rR = 1.f / (float)g.R;
+    float s_pg = 0.f, s_vf = 0.f, s_ent = 0.f, s_kl = 0.f, s_cf = 0.f;
+    float dls[4] = {0.f, 0.f, 0.f, 0.f};          // d(loss)/d(logstd_o), o = 4 lk + r, summed over this lane's samples
+
+    float *const gH1 = g.H1[trunk], *const gH2 = g.H2[trunk], *const gDZ1 = g.DZ1[trunk], *const gDZ2 = g.DZ2[trunk];
+    float *const gDOUT = g.DOUT[trunk];
+    const int64_t ntiles = (g.B + 15) >> 4;
+    const int64_t wave_global = (int64_t)wg_in_trunk * kWaves + wave, wave_stride = (int64_t)nwg_trunk * kWaves;
+
+    for (int64_t tile = wave_global; tile < ntiles; tile += wave_stride) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) asm volatile("" : "+v"(a_fw[r]), "+v"(a_bw[r]));
+        asm volatile("" : "+v"(a_l1), "+v"(a_hf), "+v"(a_hb), "+v"(a_b));
+        const int64_t srow = tile * 16 + li;
+        const bool live = srow < g.B;
+        const int64_t row = live ? srow : g.B - 1;
+
+        // ---- inputs: this lane's features lk + 4 q of its sample (the ones feature at index D), loss operands ----
+        float xr[KQ];
+#pragma unroll
+        for (int q = 0; q < KQ; q++) {
+            const int k = lk + 4 * q;
+            xr[q] = k < D ? g.X[row * D + k] : (k == D ? 1.f : 0.f);
+        }
+        // ---- layer 1 ----------------------------------------------------------------------------------------
+        f32x4 h1[HB1];
+#pragma unroll
+        for (int mb = 0; mb < HB1; mb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) h1[mb][r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < KQ; q++) {
+#pragma unroll
+            for (int mb = 0; mb < HB1; mb++) h1[mb] = MFMA16(ldf(a_l1, 4 * (4 * q * W1LD + 16 * mb)), xr[q], h1[mb]);
+        }
+#pragma unroll
+        for (int mb = 0; mb < HB1; mb++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) h1[mb][r] = fast_tanh(h1[mb][r]);
+            if (live) *(f32x4 *)(gH1 + srow * H1 + 16 * mb + 4 * lk) = h1[mb];
+        }
+
+        // ---- layer 2: the bias seeds the accumulators -----------------------------------------------------------
+        f32x4 h2[HB2];
+#pragma unroll
+        for (int m = 0; m < HB2; m++) h2[m] = ldf4(a_b, 4 * (B2S + 16 * m));
+#pragma unroll
+        for (int mb = 0; mb < HB1; mb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                // W2 rows of 16 unit blocks span 128 KB: the upper half goes through a second base
+                const int base = a_fw[r] + (mb >= 8 ? 65536 : 0), off = 4 * ((mb & 7) * 16 * H2);
+#pragma unroll
+                for (int m = 0; m < HB2; m++)
+                    h2[m] = MFMA16(ldf((m & 1) ? base ^ 64 : base, off + 4 * 32 * (m >> 1)), h1[mb][r], h2[m]);
+            }
+#pragma unroll
+        for (int m = 0; m < HB2; m++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) h2[m][r] = fast_tanh(h2[m][r]);
+            if (live) *(f32x4 *)(gH2 + srow * H2 + 16 * m + 4 * lk) = h2[m];
+        }
+
+        // ---- loss operands of this lane's outputs ----------------------------------------------------------------
+        float adv = 0.f, oldnlp = 0.f, act[4] = {0.f, 0.f, 0.f, 0.f}, ret[4] = {0.f, 0.f, 0.f, 0.f}, oldv[4] = {0.f, 0.f, 0.f, 0.f};
+        int act_i = 0;
+        if (!is_value) {
+            adv = g.ADV[row];
+            oldnlp = g.NLP[row];
+            if (gaussian) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (4 * lk + r < g.A) act[r] = ((const float *)g.ACT)[row * g.A + 4 * lk + r];
+            } else {
+                act_i = ((const int *)g.ACT)[row];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (4 * lk + r < g.R) {
+                    ret[r] = g.RET[row * g.R + 4 * lk + r];
+                    oldv[r] = g.OLDV[row * g.R + 4 * lk + r];
+                }
+        }
+
+        // ---- head: register r of lane quarter lk = output 4 lk + r ---------------------------------------------
+        f32x4 out = ldf4(a_b, 4 * BHS);
+#pragma unroll
+        for (int m = 0; m < HB2; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) out = MFMA16(ldf(a_hf, 4 * (256 * m + 16 * r)), h2[m][r], out);
+
+        // ---- loss and d(loss)/d(out) ---------------------------------------------------------------------------
+        f32x4 dout;
+#pragma unroll
+        for (int r = 0; r < 4; r++) dout[r] = 0.f;
+        auto quarters_sum = [](float v) {
+            v += __shfl_xor(v, 16, 64);
+            return v + __shfl_xor(v, 32, 64);
+        };
+        if (!is_value) {
+            float nlp, entropy_row;
+            float zq[4] = {0.f, 0.f, 0.f, 0.f}, pr[4] = {0.f, 0.f, 0.f, 0.f}, lp[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gaussian) {
+                float ss = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (4 * lk + r < g.A) {
+                        zq[r] = (act[r] - out[r]) * inv_std[r];
+                        ss += zq[r] * zq[r];
+                    }
+                ss = quarters_sum(ss);
+                nlp = 0.5f * ss + kHalfLog2Pi * (float)g.A + sum_logstd;
+                entropy_row = sum_logstd + (kHalfLog2Pi + 0.5f) * (float)g.A;
+            } else {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (4 * lk + r < g.A) mx = fmaxf(mx, out[r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float z0 = 0.f, la = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = 4 * lk + r;
+                    pr[r] = k < g.A ? expf(out[r] - mx) : 0.f;
+                    z0 += pr[r];
+                    if (k == act_i) la = out[r] - mx;
+                }
+                z0 = quarters_sum(z0);
+                la = quarters_sum(la);
+                const float logz = logf(z0);
+                nlp = logz - la;
+                float Hs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    pr[r] = pr[r] / z0;
+                    lp[r] = 4 * lk + r < g.A ? (out[r] - mx) - logz : 0.f;
+                    Hs -= pr[r] * lp[r];
+                }
+                entropy_row = quarters_sum(Hs);
+            }
+            const float ratio = expf(oldnlp - nlp);
+            const float pg1 = -adv * ratio;
+            const float pg2 = -adv * fminf(fmaxf(ratio, 1.0f - g.cliprange), 1.0f + g.cliprange);
+            const float dnlp = (live && pg1 >= pg2) ? adv * ratio * g.inv_count : 0.f;
+            if (live && lk == 0) {
+                s_pg += fmaxf(pg1, pg2);
+                const float d = nlp - oldnlp;
+                s_kl += 0.5f * (d * d);
+                s_cf += (fabsf(ratio - 1.0f) > g.cliprange) ? 1.f : 0.f;
+                s_ent += entropy_row;
+            }
+            if (gaussian) {
+                const float dent = live ? g.ent_coef * g.inv_count : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (4 * lk + r < g.A) {
+                        dout[r] = dnlp * (-zq[r] * inv_std[r]);
+                        dls[r] += dnlp * (1.f - zq[r] * zq[r]) - dent;
+                    }
+            } else {
+                const float ec = live ? g.ent_coef * g.inv_count : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = 4 * lk + r;
+                    if (k < g.A) dout[r] = dnlp * (pr[r] - (k == act_i ? 1.f : 0.f)) + ec * pr[r] * (lp[r] + entropy_row);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (4 * lk + r < g.R && live) {
+                    const float v = out[r];
+                    const float e1 = v - ret[r];
+                    if (g.upstream) {
+                        const float dv = v - oldv[r];
+                        const float vc = oldv[r] + fminf(fmaxf(dv, -g.cliprange), g.cliprange);
+                        const float e2 = vc - ret[r];
+                        const float l1 = e1 * e1, l2 = e2 * e2;
+                        s_vf += 0.5f * fmaxf(l1, l2) * rR;
+                        const float gg = (l1 >= l2) ? e1 : ((dv >= -g.cliprange && dv <= g.cliprange) ? e2 : 0.f);
+                        dout[r] = g.vf_coef * sc * gg;
+                    } else {
+                        s_vf += (e1 * e1) * rR;
+                        dout[r] = 2.f * e1 * sc;
+                    }
+                }
+        }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (4 * lk + r < O) gDOUT[srow * O + 4 * lk + r] = dout[r];
+        }
+
+        // ---- head input gradient: k-step r carries outputs 4 lk + r ---------------------------------------------
+        f32x4 dz2[HB2];
+#pragma unroll
+        for (int m = 0; m < HB2; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) dz2[m][r] = 0.f;
+        {
+            f32x4 wh[HB2];
+#pragma unroll
+            for (int m = 0; m < HB2; m++) wh[m] = ldf4(a_hb, 4 * 256 * m);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (r < O) {
+#pragma unroll
+                    for (int m = 0; m < HB2; m++) dz2[m] = MFMA16(wh[m][r], dout[r], dz2[m]);
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < HB2; m++) {
+            dz2[m] = dz2[m] - dz2[m] * (h2[m] * h2[m]);
+            if (live) *(f32x4 *)(gDZ2 + srow * H2 + 16 * m + 4 * lk) = dz2[m];
+        }
+
+        // ---- layer 2 input gradient, eight unit blocks at a time --------------------------------------------------
+        // h1 is not held in registers from layer 2 to here (64 of the 256 a lane has): the lane reads back the very
+        // addresses it wrote above, through a pointer the compiler cannot see through (it would forward the stores).
+        int64_t h1_back = row * H1 + 4 * lk;
+        asm volatile("" : "+v"(h1_back));
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            f32x4 dz1[HB1 / 2], h1b[HB1 / 2];
+#pragma unroll
+            for (int j = 0; j < HB1 / 2; j++) h1b[j] = *(const f32x4 *)(gH1 + h1_back + 16 * (8 * half + j));
+#pragma unroll
+            for (int j = 0; j < HB1 / 2; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) dz1[j][r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < HB2; m++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int base = ((m & 1) ? a_bw[r] ^ 64 : a_bw[r]) + 65536 * half, off = 4 * 32 * (m >> 1);
+#pragma unroll
+                    for (int j = 0; j < HB1 / 2; j++) dz1[j] = MFMA16(ldf(base, off + 4 * (j * 16 * H2)), dz2[m][r], dz1[j]);
+                }
+#pragma unroll
+            for (int j = 0; j < HB1 / 2; j++) {
+                const int mb = 8 * half + j;
+                dz1[j] = dz1[j] - dz1[j] * (h1b[j] * h1b[j]);
+                if (live) *(f32x4 *)(gDZ1 + srow * H1 + 16 * mb + 4 * lk) = dz1[j];
+            }
+        }
+    }
+
+    // ---- loss partial row of this workgroup: five sums, then the logstd gradients at 8 + o ------------------------
+    {
+        double vals[5 + 16];
+        vals[0] = (double)s_pg; vals[1] = (double)s_vf; vals[2] = (double)s_ent; vals[3] = (double)s_kl; vals[4] = (double)s_cf;
+#pragma unroll
+        for (int o = 0; o < 16; o++) vals[5 + o] = (lk == (o >> 2)) ? (double)dls[o & 3] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 21; k++) {
+            const double v = wave_sum(vals[k]);
+            if (lane == 0) red[wave * 24 + k] = v;
+        }
+        __syncthreads();
+        if (tid < 21) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < kWaves; w++) v += red[w * 24 + tid];
+            g.loss_partial[(int64_t)blockIdx.x * kLossStride + (tid < 5 ? tid : 8 + (tid - 5))] = v;
+        }
+        if (tid >= 5 && tid < 8) g.loss_partial[(int64_t)blockIdx.x * kLossStride + tid] = 0.0;
+    }
+}
+
+bool mlp_fused256_supported(const ppo2hip_policy_desc &d) {
+    if (d.kind != PPO2HIP_POLICY_MLP || d.hidden1 != f256::H1 || d.hidden2 != f256::H2) return false;
+    return d.ob_dim >= 1 && d.ob_dim + 1 <= 4 * f256::KQ && d.ac_dim <= 16 && d.nvalue <= 8;
+}
+
+int mlp_fused256_grid() { return 256; }
+
+size_t mlp_fused256_loss_bytes() { return align_up((size_t)mlp_fused256_grid() * f256::kLossStride * sizeof(double), 256); }
+
+int mlp_fused256_chain(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params, const FusedOffsets &fo,
+                       const Fused256Buffers &b, int64_t B, float cliprange, double inv_count, float *losses, float *dlogstd,
+                       hipStream_t s) {
+    Fused256Args g;
+    g.X = b.X; g.ACT = b.ACT; g.RET = b.RET; g.OLDV = b.OLDV; g.NLP = b.NLP; g.ADV = b.ADV; g.B = B; g.params = params;
+    g.a_w1 = fo.a_w1; g.a_w2 = fo.a_w2; g.a_wh = fo.a_wh; g.v_w1 = fo.v_w1; g.v_w2 = fo.v_w2; g.v_wh = fo.v_wh; g.logstd_off = fo.logstd;
+    g.D = d.ob_dim; g.A = d.ac_dim; g.R = d.nvalue; g.dist = d.dist; g.upstream = lc.upstream;
+    g.cliprange = cliprange; g.ent_coef = lc.ent_coef; g.vf_coef = lc.upstream ? lc.vf_coef : 1.0f; g.inv_count = (float)inv_count;
+    for (int t = 0; t < 2; t++) { g.H1[t] = b.H1[t]; g.H2[t] = b.H2[t]; g.DZ1[t] = b.DZ1[t]; g.DZ2[t] = b.DZ2[t]; g.DOUT[t] = b.DOUT[t]; }
+    g.loss_partial = b.loss_partial;
+    const int grid = mlp_fused256_grid();
+    hipLaunchKernelGGL(mlp_fused256_kernel, dim3(grid), dim3(f256::kThreads), 0, s, g);
+    int rc = check_launch("mlp_fused256_kernel");
+    if (rc) return rc;
+    return fused_loss_finalize(b.loss_partial, grid, d.dist == PPO2HIP_DIST_GAUSSIAN ? d.ac_dim : 0, inv_count, losses, dlogstd, s);
+}
+
+}  // namespace ppo2hip

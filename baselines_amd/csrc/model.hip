@@ -119,6 +119,8 @@ struct MlpBuf {
     float *X, *RET, *OLDV, *NLP, *ADV;
     void *ACT;
     float *H1a, *H2a, *PI, *H1v, *H2v, *VF, *dPI, *dVF, *dZ2, *dZ1, *slabs;
+    float *dZ2v, *dZ1v;          // the value trunk's own gradient rows where both trunks run in one launch
+    double *loss256;
     char *fused;
     size_t fused_bytes;
     double *loss_partial;
@@ -156,6 +158,12 @@ static void carve_mlp(const ppo2hip_policy_desc &d, int64_t B, Carver &c, MlpBuf
     if (mlp_fused_supported(d)) w.fused_bytes = mlp_fused_workspace_bytes();
     if (mlp_fused16_supported(d) && mlp_fused16_workspace_bytes() > w.fused_bytes) w.fused_bytes = mlp_fused16_workspace_bytes();
     w.fused = c.take<char>(w.fused_bytes);
+    w.dZ2v = w.dZ1v = nullptr;
+    w.loss256 = nullptr;
+    if (mlp_fused256_supported(d)) {
+        w.dZ2v = c.take<float>(B * h2); w.dZ1v = c.take<float>(B * h1);
+        w.loss256 = (double *)c.take<char>(mlp_fused256_loss_bytes());
+    }
 }
 
 static int mlp_forward(const ppo2hip_policy_desc &d, const Layout &L, const float *p, const MlpBuf &w, int64_t B,
@@ -198,6 +206,7 @@ static int mlp_path_choice(const ppo2hip_policy_desc &d, const ppo2hip_rollout &
     const char *e = getenv("PPO2HIP_MLP_PATH");
     const bool f16 = mlp_fused16_supported(d) && mlp_fused16_fits(d, ro, B), f32 = mlp_fused_supported(d);
     if (e && std::strcmp(e, "layered") == 0) return 0;
+    if (mlp_fused256_supported(d)) return 256;
     if (e && std::strcmp(e, "fused32") == 0 && f32) return 32;
     if (e && std::strcmp(e, "fused16") == 0 && f16) return 16;
     return f16 ? 16 : (f32 ? 32 : 0);
@@ -217,7 +226,7 @@ static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
     const int D = d.ob_dim, h1 = d.hidden1, h2 = d.hidden2, A = d.ac_dim, R = d.nvalue;
     const bool gauss = d.dist == PPO2HIP_DIST_GAUSSIAN;
     const int path = mlp_path_choice(d, ro, B);
-    if (path) {
+    if (path == 16 || path == 32) {
         FusedOffsets fo{L.off("pi_fc1/w"), L.off("pi_fc2/w"), L.off("pi/w"), L.off("vf_fc1/w"), L.off("vf_fc2/w"),
                         L.off("vf/w"), gauss ? L.off("logstd") : 0};
         if (path == 16) {
@@ -236,6 +245,25 @@ static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
     g.neglogpacs = w.NLP; g.advs = w.ADV; g.masks = nullptr;
     int rc;
     if ((rc = gather_minibatch(g, s))) return rc;
+    if (path == 256) {
+        // forward, loss and both input-gradient products of both trunks in one launch; the weight gradients from its outputs
+        FusedOffsets fo{L.off("pi_fc1/w"), L.off("pi_fc2/w"), L.off("pi/w"), L.off("vf_fc1/w"), L.off("vf_fc2/w"),
+                        L.off("vf/w"), gauss ? L.off("logstd") : 0};
+        Fused256Buffers fb;
+        fb.X = w.X; fb.ACT = w.ACT; fb.RET = w.RET; fb.OLDV = w.OLDV; fb.NLP = w.NLP; fb.ADV = w.ADV;
+        fb.H1[0] = w.H1a; fb.H2[0] = w.H2a; fb.DZ1[0] = w.dZ1; fb.DZ2[0] = w.dZ2; fb.DOUT[0] = w.dPI;
+        fb.H1[1] = w.H1v; fb.H2[1] = w.H2v; fb.DZ1[1] = w.dZ1v; fb.DZ2[1] = w.dZ2v; fb.DOUT[1] = w.dVF;
+        fb.loss_partial = w.loss256;
+        if ((rc = mlp_fused256_chain(d, lc, p, fo, fb, B, cliprange, inv_count, losses, gauss ? grads + L.off("logstd") : nullptr, s))) return rc;
+        for (int t = 0; t < 2; t++) {
+            const int N = t ? R : A;
+            const int64_t o1 = L.off(t ? "vf_fc1/w" : "pi_fc1/w"), o2 = L.off(t ? "vf_fc2/w" : "pi_fc2/w"), oh = L.off(t ? "vf/w" : "pi/w");
+            if ((rc = fc_wgrad_into(fb.H2[t], h2, fb.DOUT[t], N, B, h2, N, w, grads + oh, s))) return rc;
+            if ((rc = fc_wgrad_into(fb.H1[t], h1, fb.DZ2[t], h2, B, h1, h2, w, grads + o2, s))) return rc;
+            if ((rc = fc_wgrad_into(w.X, D, fb.DZ1[t], h1, B, D, h1, w, grads + o1, s))) return rc;
+        }
+        return 0;
+    }
     if ((rc = mlp_forward(d, L, p, w, B, w.PI, w.VF, s))) return rc;
     LossArgs la;
     la.dist = d.dist; la.ac_dim = A; la.nvalue = R; la.B = B; la.pi = w.PI;
