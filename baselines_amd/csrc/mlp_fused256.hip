@@ -148,10 +148,23 @@ __global__ __launch_bounds__(f256::kThreads, 2) void mlp_fused256_kernel(Fused25
         for (int mb = 0; mb < HB1; mb++)
 #pragma unroll
             for (int r = 0; r < 4; r++) h1[mb][r] = 0.f;
+        // Every product below runs as a software pipeline over its k-steps: the weight operands of step s + 1 are
+        // read from LDS while the matrix cores work on step s (a wave has one other wave on its SIMD to hide behind).
+        {
+            float w[2][HB1];
 #pragma unroll
-        for (int q = 0; q < KQ; q++) {
+            for (int mb = 0; mb < HB1; mb++) w[0][mb] = ldf(a_l1, 4 * (16 * mb));
 #pragma unroll
-            for (int mb = 0; mb < HB1; mb++) h1[mb] = MFMA16(ldf(a_l1, 4 * (4 * q * W1LD + 16 * mb)), xr[q], h1[mb]);
+            for (int q = 0; q < KQ; q++) {
+                if (q + 1 < KQ) {
+#pragma unroll
+                    for (int mb = 0; mb < HB1; mb++) w[(q + 1) & 1][mb] = ldf(a_l1, 4 * (4 * (q + 1) * W1LD + 16 * mb));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mb = 0; mb < HB1; mb++) h1[mb] = MFMA16(w[q & 1][mb], xr[q], h1[mb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int mb = 0; mb < HB1; mb++) {
@@ -164,16 +177,25 @@ __global__ __launch_bounds__(f256::kThreads, 2) void mlp_fused256_kernel(Fused25
         f32x4 h2[HB2];
 #pragma unroll
         for (int m = 0; m < HB2; m++) h2[m] = ldf4(a_b, 4 * (B2S + 16 * m));
-#pragma unroll
-        for (int mb = 0; mb < HB1; mb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
+        {
+            float w[2][HB2];
+            auto fetch = [&](int s, float (&o)[HB2]) {      // k-step s = (mb, r): unit 16 mb + 4 lk + r against all 128 outputs
+                const int mb = s >> 2, r = s & 3;
                 // W2 rows of 16 unit blocks span 128 KB: the upper half goes through a second base
                 const int base = a_fw[r] + (mb >= 8 ? 65536 : 0), off = 4 * ((mb & 7) * 16 * H2);
 #pragma unroll
-                for (int m = 0; m < HB2; m++)
-                    h2[m] = MFMA16(ldf((m & 1) ? base ^ 64 : base, off + 4 * 32 * (m >> 1)), h1[mb][r], h2[m]);
+                for (int m = 0; m < HB2; m++) o[m] = ldf((m & 1) ? base ^ 64 : base, off + 4 * 32 * (m >> 1));
+            };
+            fetch(0, w[0]);
+#pragma unroll
+            for (int s = 0; s < 4 * HB1; s++) {
+                if (s + 1 < 4 * HB1) fetch(s + 1, w[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < HB2; m++) h2[m] = MFMA16(w[s & 1][m], h1[s >> 2][s & 3], h2[m]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
 #pragma unroll
         for (int m = 0; m < HB2; m++) {
 #pragma unroll
@@ -205,10 +227,20 @@ __global__ __launch_bounds__(f256::kThreads, 2) void mlp_fused256_kernel(Fused25
 
         // ---- head: register r of lane quarter lk = output 4 lk + r ---------------------------------------------
         f32x4 out = ldf4(a_b, 4 * BHS);
+        {
+            f32x4 part[3];          // four chains instead of one of 32 dependent products
 #pragma unroll
-        for (int m = 0; m < HB2; m++)
+            for (int c = 0; c < 3; c++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) out = MFMA16(ldf(a_hf, 4 * (256 * m + 16 * r)), h2[m][r], out);
+                for (int r = 0; r < 4; r++) part[c][r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < HB2; m++) {
+                out = MFMA16(ldf(a_hf, 4 * (256 * m)), h2[m][0], out);
+#pragma unroll
+                for (int r = 1; r < 4; r++) part[r - 1] = MFMA16(ldf(a_hf, 4 * (256 * m + 16 * r)), h2[m][r], part[r - 1]);
+            }
+            out = (out + part[0]) + (part[1] + part[2]);
+        }
 
         // ---- loss and d(loss)/d(out) ---------------------------------------------------------------------------
         f32x4 dout;
@@ -350,14 +382,22 @@ __global__ __launch_bounds__(f256::kThreads, 2) void mlp_fused256_kernel(Fused25
             for (int j = 0; j < HB1 / 2; j++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) dz1[j][r] = 0.f;
+            float w[2][HB1 / 2];
+            auto fetch = [&](int s, float (&o)[HB1 / 2]) {  // k-step s = (m, r): output 16 m + 4 lk + r against this half's units
+                const int m = s >> 2, r = s & 3;
+                const int base = ((m & 1) ? a_bw[r] ^ 64 : a_bw[r]) + 65536 * half, off = 4 * 32 * (m >> 1);
 #pragma unroll
-            for (int m = 0; m < HB2; m++)
+                for (int j = 0; j < HB1 / 2; j++) o[j] = ldf(base, off + 4 * (j * 16 * H2));
+            };
+            fetch(0, w[0]);
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int base = ((m & 1) ? a_bw[r] ^ 64 : a_bw[r]) + 65536 * half, off = 4 * 32 * (m >> 1);
+            for (int s = 0; s < 4 * HB2; s++) {
+                if (s + 1 < 4 * HB2) fetch(s + 1, w[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < HB1 / 2; j++) dz1[j] = MFMA16(ldf(base, off + 4 * (j * 16 * H2)), dz2[m][r], dz1[j]);
-                }
+                for (int j = 0; j < HB1 / 2; j++) dz1[j] = MFMA16(w[s & 1][j], dz2[s >> 2][s & 3], dz1[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int j = 0; j < HB1 / 2; j++) {
                 const int mb = 8 * half + j;
