@@ -134,9 +134,14 @@ struct Fused256Buffers {
     const float *RET, *OLDV, *NLP, *ADV;
     float *H1[2], *H2[2], *DZ1[2], *DZ2[2], *DOUT[2];      // per trunk (policy, value)
     double *loss_partial;                     // mlp_fused256_loss_bytes()
+    float *wslabs;                            // mlp_fused256_wgrad_bytes(): per-workgroup weight-gradient sums
 };
 bool mlp_fused256_supported(const ppo2hip_policy_desc &d);
 size_t mlp_fused256_loss_bytes();
+size_t mlp_fused256_wgrad_bytes();
+// every weight and bias gradient of both trunks from the rows mlp_fused256_chain wrote (two launches)
+int mlp_fused256_wgrad(const ppo2hip_policy_desc &d, const FusedOffsets &fo, const Fused256Buffers &b, int64_t B, float *grads,
+                       hipStream_t s);
 int mlp_fused256_chain(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const float *params, const FusedOffsets &fo,
                        const Fused256Buffers &b, int64_t B, float cliprange, double inv_count, float *losses, float *dlogstd,
                        hipStream_t s);

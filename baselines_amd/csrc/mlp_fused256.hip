@@ -429,6 +429,232 @@ __global__ __launch_bounds__(f256::kThreads, 2) void mlp_fused256_kernel(Fused25
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// All weight and bias gradients of a trunk from what the chain kernel wrote, each activation row read once.
+//
+// A workgroup owns a run of samples and, over its eight waves, one full set of accumulators:
+//   dW2 = h1^T dz2 (256 x 128)   wave (wr, wc) = (wave >> 1, wave & 1) holds rows 64 wr.., columns 64 wc..: 4 x 4 blocks
+//   dW1 = [x 1]^T dz1 (32 x 256) wave w holds unit blocks 2 w, 2 w + 1 against both feature blocks; the ones feature at
+//                                index D makes row D the bias gradient, as the arena lays (w, b) out
+//   dWh = h2^T dout (128 x 16)   wave w holds unit block w
+//   db2, dbh                     a product with the 16 x 4 operand "row 0 is all ones, the rest zero": row 0 of the result is
+//                                the column sum; wave w holds db2's column block w, wave 0 dbh
+// Samples run along k, four per MFMA step, sixteen per slab.  The six operand tiles of a slab (58 KB) are double-buffered
+// in LDS: while the matrix cores work on slab i, slab i + 1 travels HBM -> registers -> the other buffer, one barrier
+// per slab.  Row pitches are 16 mod 64 floats so the four sample rows of an operand read fall on distinct banks.
+// Each workgroup writes its sums to a slab of its own; a second launch adds the slabs in a fixed order.
+namespace w256 {
+constexpr int kThreads = 512, kWaves = 8, KS = 16;
+constexpr int P1 = 272, P2 = 144, PX = 48, PO = 16;
+constexpr int oH1 = 0, oDZ1 = oH1 + KS * P1, oH2 = oDZ1 + KS * P1, oDZ2 = oH2 + KS * P2, oX = oDZ2 + KS * P2, oDO = oX + KS * PX;
+constexpr int STAGE = oDO + KS * PO;
+static_assert(2 * STAGE * 4 <= 160 * 1024, "LDS budget");
+// a workgroup's slab: [32 x 256] dW1 rows (feature, the ones feature among them) | [257 x 128] dW2, db2 | [129 x 16] dWh, dbh
+constexpr int S1 = 0, S2 = S1 + 32 * 256, S3 = S2 + 257 * 128, SLAB = S3 + 129 * 16;
+constexpr int kSlabsPerTrunk = 128;
+}  // namespace w256
+
+struct Wgrad256Args {
+    const float *X;
+    const float *H1[2], *H2[2], *DZ1[2], *DZ2[2], *DOUT[2];
+    int64_t B, rows_per_wg;
+    int D, A, R;
+    float *slabs;            // [2][kSlabsPerTrunk][SLAB]
+};
+
+__global__ __launch_bounds__(w256::kThreads, 2) void mlp_wgrad256_kernel(Wgrad256Args g) {
+    using namespace w256;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int trunk = blockIdx.x & 1, wg = blockIdx.x >> 1;
+    const int64_t s_beg = (int64_t)wg * g.rows_per_wg;
+    if (s_beg >= g.B) return;                                  // the reduction knows how many slabs were written
+    const int64_t s_end = s_beg + g.rows_per_wg < g.B ? s_beg + g.rows_per_wg : g.B;
+    const int D = g.D, O = trunk ? g.R : g.A;
+    const float *const gH1 = g.H1[trunk], *const gH2 = g.H2[trunk], *const gDZ1 = g.DZ1[trunk], *const gDZ2 = g.DZ2[trunk];
+    const float *const gDO = g.DOUT[trunk], *const gX = g.X;
+
+    // ---- HBM -> registers -> LDS: what this thread carries of a slab ---------------------------------------------------
+    const int r64 = tid >> 6, c64 = tid & 63;        // H1 / DZ1: rows r64 and r64 + 8, float4 column c64
+    const int r32 = tid >> 5, c32 = tid & 31;        // H2 / DZ2: row r32, float4 column c32;  X: row r32, feature c32
+    const int r16 = (tid >> 4) & 15, c16 = tid & 15; // DOUT: row r16, output c16 (threads 0..255)
+    f32x4 pH1[2], pDZ1[2], pH2, pDZ2;
+    float pX, pDO;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int64_t s0) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int64_t r = s0 + r64 + 8 * e;
+            const bool ok = r < s_end;
+            pH1[e] = ok ? *(const f32x4 *)(gH1 + r * 256 + 4 * c64) : zero4;
+            pDZ1[e] = ok ? *(const f32x4 *)(gDZ1 + r * 256 + 4 * c64) : zero4;
+        }
+        const int64_t r = s0 + r32;
+        const bool ok = r < s_end;
+        pH2 = ok ? *(const f32x4 *)(gH2 + r * 128 + 4 * c32) : zero4;
+        pDZ2 = ok ? *(const f32x4 *)(gDZ2 + r * 128 + 4 * c32) : zero4;
+        pX = ok ? (c32 < D ? gX[r * D + c32] : (c32 == D ? 1.f : 0.f)) : 0.f;
+        const int64_t ro = s0 + r16;
+        pDO = (tid < 256 && ro < s_end && c16 < O) ? gDO[ro * O + c16] : 0.f;
+    };
+    auto stash = [&](float *st) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            *(f32x4 *)(st + oH1 + (r64 + 8 * e) * P1 + 4 * c64) = pH1[e];
+            *(f32x4 *)(st + oDZ1 + (r64 + 8 * e) * P1 + 4 * c64) = pDZ1[e];
+        }
+        *(f32x4 *)(st + oH2 + r32 * P2 + 4 * c32) = pH2;
+        *(f32x4 *)(st + oDZ2 + r32 * P2 + 4 * c32) = pDZ2;
+        st[oX + r32 * PX + c32] = pX;
+        if (c32 < PX - 32) st[oX + r32 * PX + 32 + c32] = 0.f;
+        if (tid < 256) st[oDO + r16 * PO + c16] = pDO;
+    };
+
+    f32x4 acc2[4][4], acc1[2][2], acch, accb2, accbh;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc2[a][b][r] = 0.f;
+#pragma unroll
+        for (int f = 0; f < 2; f++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) acc1[f][c][r] = 0.f;
+        acch[r] = 0.f; accb2[r] = 0.f; accbh[r] = 0.f;
+    }
+    const int wr = wave >> 1, wc = wave & 1;
+    const float ones_row = li == 0 ? 1.f : 0.f;
+    // lane bases (floats) of the operand reads inside a stage; + (4 kk) rows per k-step
+    const int bA2 = oH1 + lk * P1 + 64 * wr + li, bB2 = oDZ2 + lk * P2 + 64 * wc + li;
+    const int bA1 = oX + lk * PX + li, bB1 = oDZ1 + lk * P1 + 32 * wave + li;
+    const int bAh = oH2 + lk * P2 + 16 * wave + li, bBh = oDO + lk * PO + li, bBb = oDZ2 + lk * P2 + 16 * wave + li;
+
+    fetch(s_beg);
+    stash(lds);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t s0 = s_beg; s0 < s_end; s0 += KS) {
+        const bool more = s0 + KS < s_end;
+        if (more) fetch(s0 + KS);
+        const float *st = lds + buf * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < KS / 4; kk++) {
+            float a2[4], b2[4], a1[2], b1[2];
+#pragma unroll
+            for (int a = 0; a < 4; a++) a2[a] = st[bA2 + 4 * kk * P1 + 16 * a];
+#pragma unroll
+            for (int b = 0; b < 4; b++) b2[b] = st[bB2 + 4 * kk * P2 + 16 * b];
+#pragma unroll
+            for (int f = 0; f < 2; f++) a1[f] = st[bA1 + 4 * kk * PX + 16 * f];
+#pragma unroll
+            for (int c = 0; c < 2; c++) b1[c] = st[bB1 + 4 * kk * P1 + 16 * c];
+            const float ah = st[bAh + 4 * kk * P2], bh = st[bBh + 4 * kk * PO], bb = st[bBb + 4 * kk * P2];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc2[a][b] = MFMA16(a2[a], b2[b], acc2[a][b]);
+#pragma unroll
+            for (int f = 0; f < 2; f++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) acc1[f][c] = MFMA16(a1[f], b1[c], acc1[f][c]);
+            acch = MFMA16(ah, bh, acch);
+            accb2 = MFMA16(ones_row, bb, accb2);
+            if (wave == 0) accbh = MFMA16(ones_row, bh, accbh);
+        }
+        if (more) stash(lds + (buf ^ 1) * STAGE);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- this workgroup's slab: result register r of lane (li, lk) = row 4 lk + r, column li of its block ---------------
+    float *slab = g.slabs + ((int64_t)trunk * kSlabsPerTrunk + wg) * SLAB;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) slab[S2 + (64 * wr + 16 * a + 4 * lk + r) * 128 + 64 * wc + 16 * b + li] = acc2[a][b][r];
+#pragma unroll
+        for (int f = 0; f < 2; f++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) slab[S1 + (16 * f + 4 * lk + r) * 256 + 32 * wave + 16 * c + li] = acc1[f][c][r];
+        slab[S3 + (16 * wave + 4 * lk + r) * 16 + li] = acch[r];
+    }
+    if (lk == 0) {
+        slab[S2 + 256 * 128 + 16 * wave + li] = accb2[0];
+        if (wave == 0) slab[S3 + 128 * 16 + li] = accbh[0];
+    }
+}
+
+// grads[...] = sum over a trunk's slabs, in slab order: 64 consecutive elements x 8 slab groups per workgroup
+struct Wgrad256Reduce {
+    const float *slabs;
+    float *grads;
+    int64_t o_w1[2], o_w2[2], o_wh[2];
+    int nslabs, D, O[2];
+};
+__global__ __launch_bounds__(512) void mlp_wgrad256_reduce_kernel(Wgrad256Reduce g) {
+    using namespace w256;
+    __shared__ float part[8][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, trunk = blockIdx.y;
+    const int O = g.O[trunk], n1 = (g.D + 1) * 256, n2 = 257 * 128, n3 = 129 * O;
+    const int e = blockIdx.x * 64 + lane;
+    int so = -1;
+    int64_t dst = 0;
+    if (e < n1) {
+        so = S1 + e; dst = g.o_w1[trunk] + e;
+    } else if (e < n1 + n2) {
+        so = S2 + (e - n1); dst = g.o_w2[trunk] + (e - n1);
+    } else if (e < n1 + n2 + n3) {
+        const int q = e - n1 - n2;
+        so = S3 + (q / O) * 16 + q % O; dst = g.o_wh[trunk] + q;
+    }
+    float s = 0.f;
+    if (so >= 0) {
+        const float *base = g.slabs + (int64_t)trunk * kSlabsPerTrunk * SLAB + so;
+        for (int z0 = grp; z0 < g.nslabs; z0 += 32) {
+            float x[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) x[u] = z0 + 8 * u < g.nslabs ? base[(int64_t)(z0 + 8 * u) * SLAB] : 0.f;
+            s += (x[0] + x[1]) + (x[2] + x[3]);
+        }
+    }
+    part[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && so >= 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) t += part[q][lane];
+        g.grads[dst] = t;
+    }
+}
+
+size_t mlp_fused256_wgrad_bytes() { return align_up((size_t)2 * w256::kSlabsPerTrunk * w256::SLAB * sizeof(float), 256); }
+
+int mlp_fused256_wgrad(const ppo2hip_policy_desc &d, const FusedOffsets &fo, const Fused256Buffers &b, int64_t B, float *grads,
+                       hipStream_t s) {
+    using namespace w256;
+    Wgrad256Args g;
+    g.X = b.X;
+    for (int t = 0; t < 2; t++) { g.H1[t] = b.H1[t]; g.H2[t] = b.H2[t]; g.DZ1[t] = b.DZ1[t]; g.DZ2[t] = b.DZ2[t]; g.DOUT[t] = b.DOUT[t]; }
+    g.B = B;
+    g.rows_per_wg = (int64_t)ceil_div(ceil_div(B > 0 ? B : 1, (int64_t)kSlabsPerTrunk), (int64_t)KS) * KS;
+    g.D = d.ob_dim; g.A = d.ac_dim; g.R = d.nvalue; g.slabs = b.wslabs;
+    hipLaunchKernelGGL(mlp_wgrad256_kernel, dim3(2 * kSlabsPerTrunk), dim3(kThreads), 0, s, g);
+    int rc = check_launch("mlp_wgrad256_kernel");
+    if (rc) return rc;
+    Wgrad256Reduce r;
+    r.slabs = b.wslabs; r.grads = grads;
+    r.o_w1[0] = fo.a_w1; r.o_w2[0] = fo.a_w2; r.o_wh[0] = fo.a_wh; r.o_w1[1] = fo.v_w1; r.o_w2[1] = fo.v_w2; r.o_wh[1] = fo.v_wh;
+    r.nslabs = (int)ceil_div(B > 0 ? B : 1, g.rows_per_wg); r.D = d.ob_dim; r.O[0] = d.ac_dim; r.O[1] = d.nvalue;
+    const int omax = d.ac_dim > d.nvalue ? d.ac_dim : d.nvalue;
+    const int nmax = (d.ob_dim + 1) * 256 + 257 * 128 + 129 * omax;
+    hipLaunchKernelGGL(mlp_wgrad256_reduce_kernel, dim3((unsigned)ceil_div(nmax, 64), 2), dim3(512), 0, s, r);
+    return check_launch("mlp_wgrad256_reduce_kernel");
+}
+
 bool mlp_fused256_supported(const ppo2hip_policy_desc &d) {
     if (d.kind != PPO2HIP_POLICY_MLP || d.hidden1 != f256::H1 || d.hidden2 != f256::H2) return false;
     return d.ob_dim >= 1 && d.ob_dim + 1 <= 4 * f256::KQ && d.ac_dim <= 16 && d.nvalue <= 8;

@@ -121,6 +121,7 @@ struct MlpBuf {
     float *H1a, *H2a, *PI, *H1v, *H2v, *VF, *dPI, *dVF, *dZ2, *dZ1, *slabs;
     float *dZ2v, *dZ1v;          // the value trunk's own gradient rows where both trunks run in one launch
     double *loss256;
+    float *wslabs256;
     char *fused;
     size_t fused_bytes;
     double *loss_partial;
@@ -160,7 +161,9 @@ static void carve_mlp(const ppo2hip_policy_desc &d, int64_t B, Carver &c, MlpBuf
     w.fused = c.take<char>(w.fused_bytes);
     w.dZ2v = w.dZ1v = nullptr;
     w.loss256 = nullptr;
+    w.wslabs256 = nullptr;
     if (mlp_fused256_supported(d)) {
+        w.wslabs256 = (float *)c.take<char>(mlp_fused256_wgrad_bytes());
         w.dZ2v = c.take<float>(B * h2); w.dZ1v = c.take<float>(B * h1);
         w.loss256 = (double *)c.take<char>(mlp_fused256_loss_bytes());
     }
@@ -253,8 +256,9 @@ static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
         fb.X = w.X; fb.ACT = w.ACT; fb.RET = w.RET; fb.OLDV = w.OLDV; fb.NLP = w.NLP; fb.ADV = w.ADV;
         fb.H1[0] = w.H1a; fb.H2[0] = w.H2a; fb.DZ1[0] = w.dZ1; fb.DZ2[0] = w.dZ2; fb.DOUT[0] = w.dPI;
         fb.H1[1] = w.H1v; fb.H2[1] = w.H2v; fb.DZ1[1] = w.dZ1v; fb.DZ2[1] = w.dZ2v; fb.DOUT[1] = w.dVF;
-        fb.loss_partial = w.loss256;
+        fb.loss_partial = w.loss256; fb.wslabs = w.wslabs256;
         if ((rc = mlp_fused256_chain(d, lc, p, fo, fb, B, cliprange, inv_count, losses, gauss ? grads + L.off("logstd") : nullptr, s))) return rc;
+        if (!getenv("PPO2HIP_F256_GEMM_WGRAD")) return mlp_fused256_wgrad(d, fo, fb, B, grads, s);
         for (int t = 0; t < 2; t++) {
             const int N = t ? R : A;
             const int64_t o1 = L.off(t ? "vf_fc1/w" : "pi_fc1/w"), o2 = L.off(t ? "vf_fc2/w" : "pi_fc2/w"), oh = L.off(t ? "vf/w" : "pi/w");
