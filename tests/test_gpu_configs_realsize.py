@@ -254,3 +254,47 @@ def test_cnn_lstm_full_depth_env_sequences(mods):
         sum_l += losses.cpu().numpy()[:5]
     _check_grads(spec, full_g, sum_g, "128 envs at once vs 8 x 16 envs")
     np.testing.assert_allclose(full_l, sum_l, rtol=5e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("B", [131072, 100003])
+def test_fork_network_at_benchmark_minibatch_size(mods, B, monkeypatch):
+    """The fork's own network (two 256-128 tanh trunks, five value channels, baselines/ppo2/policies.py:139-151) on a
+    minibatch of the benchmark's size (and on one that is no multiple of any tile): the fused chain + fused
+    weight-gradient route against the float64 restatement, and against the layer-by-layer route of the same library."""
+    hip, lib = mods["hip"], mods["lib"]
+    D, A, R, T, E = 17, 6, 5, 64, 2048
+    spec = hip.PolicySpec(lib.POLICY_MLP, lib.DIST_GAUSSIAN, A, R, ob_dim=D, hidden=(256, 128), order=lib.ORDER_FORK)
+    shapes = tfgraph.mlp_param_shapes(D, (256, 128), A, R, True, "fork")
+    params = util.make_params(shapes, 61, pi_scale=0.5, jitter=0.02)
+    ro = util.synthetic_mlp_rollout(np.random.RandomState(62), T, E, D, A, R, True, params, nlp_noise=0.2)
+    _, rets = scan.gae(ro["rewards"], ro["values"], ro["dones"], ro["last_values"], ro["last_dones"], 0.99, 0.95)
+    advs_tm = (rets - ro["values"]).sum(axis=2).astype(np.float32)
+    idx = np.random.RandomState(63).permutation(T * E)[:B].astype(np.int32)
+    lossd = lib.LossDesc(0.0, 0.5, 0.5, 0)
+
+    f = lambda a: scan.sf01(a)[idx]
+    oracle = tfgraph.TrainOracle(params, "mlp", "gaussian", tfgraph.LossCfg(0.0, 0.5, 0.5, False))
+    o_losses = oracle.train(3e-4, 0.2, f(ro["obs"]), f(rets), None, f(ro["actions"]), f(ro["values"]), f(advs_tm),
+                            f(ro["neglogpacs"]), apply=False)
+    want = np.concatenate([oracle.last_grads[name].numpy().ravel() for name, _, _ in spec.vars])
+
+    theta = dev(util.flatten_params(params, spec))
+    ws = torch.empty(spec.grad_workspace_bytes(B), dtype=torch.uint8, device="cuda")
+    rref = hip.RolloutRef(spec, dev(ro["obs"]), dev(ro["actions"]), dev(rets), dev(ro["values"]), dev(ro["neglogpacs"]),
+                          dev(advs_tm), T, E)
+    d_idx = dev(idx)
+    stats = hip.adv_stats(rref.keep[5], d_idx, B, 1, T, E)
+    got = {}
+    for route in ("default", "layered"):
+        if route == "layered":
+            monkeypatch.setenv("PPO2HIP_MLP_PATH", "layered")
+        grads = torch.full((spec.nparams,), float("nan"), device="cuda")
+        losses = torch.zeros(8, device="cuda")
+        hip.ppo_grad(spec, lossd, theta, rref, d_idx, B, stats, 0.2, 1.0 / B, grads, losses, ws)
+        torch.cuda.synchronize()
+        got[route] = (grads.cpu().numpy(), losses.cpu().numpy()[:5])
+    for route, (g, l) in got.items():
+        assert np.all(np.isfinite(g)), route
+        np.testing.assert_allclose(l, o_losses, rtol=5e-5, atol=1e-7, err_msg=route)
+        _check_grads(spec, g, want, route)
+    _check_grads(spec, got["default"][0], got["layered"][0], "fused against layered", tol=2e-5)
