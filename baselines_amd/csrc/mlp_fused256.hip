@@ -531,39 +531,57 @@ __global__ __launch_bounds__(w256::kThreads, 2) void mlp_wgrad256_kernel(Wgrad25
     const int bA1 = oX + lk * PX + li, bB1 = oDZ1 + lk * P1 + 32 * wave + li;
     const int bAh = oH2 + lk * P2 + 16 * wave + li, bBh = oDO + lk * PO + li, bBb = oDZ2 + lk * P2 + 16 * wave + li;
 
+    // operand registers of one k-step (four sample rows): 4 + 4 for dW2, 2 + 2 for dW1, head unit block, dout, dz2 block
+    struct Ops { float a2[4], b2[4], a1[2], b1[2], ah, bh, bb; };
+    auto read_ops = [&](const float *st, int kk, Ops &o) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) o.a2[a] = st[bA2 + 4 * kk * P1 + 16 * a];
+#pragma unroll
+        for (int b = 0; b < 4; b++) o.b2[b] = st[bB2 + 4 * kk * P2 + 16 * b];
+#pragma unroll
+        for (int f = 0; f < 2; f++) o.a1[f] = st[bA1 + 4 * kk * PX + 16 * f];
+#pragma unroll
+        for (int c = 0; c < 2; c++) o.b1[c] = st[bB1 + 4 * kk * P1 + 16 * c];
+        o.ah = st[bAh + 4 * kk * P2]; o.bh = st[bBh + 4 * kk * PO]; o.bb = st[bBb + 4 * kk * P2];
+    };
+    auto multiply = [&](const Ops &o) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc2[a][b] = MFMA16(o.a2[a], o.b2[b], acc2[a][b]);
+#pragma unroll
+        for (int f = 0; f < 2; f++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) acc1[f][c] = MFMA16(o.a1[f], o.b1[c], acc1[f][c]);
+        acch = MFMA16(o.ah, o.bh, acch);
+        accb2 = MFMA16(ones_row, o.bb, accb2);
+        if (wave == 0) accbh = MFMA16(ones_row, o.bh, accbh);
+    };
+
+    // Slab i is multiplied out of one buffer while slab i + 1 goes from registers into the other in the middle of the
+    // iteration (nobody reads that buffer since the last barrier) and slab i + 2 leaves HBM for the registers right
+    // after; the operand registers of k-step kk + 1 are read while the matrix cores work on k-step kk.
     fetch(s_beg);
     stash(lds);
+    if (s_beg + KS < s_end) fetch(s_beg + KS);
     __syncthreads();
     int buf = 0;
     for (int64_t s0 = s_beg; s0 < s_end; s0 += KS) {
-        const bool more = s0 + KS < s_end;
-        if (more) fetch(s0 + KS);
         const float *st = lds + buf * STAGE;
+        Ops o[2];
+        read_ops(st, 0, o[0]);
 #pragma unroll
         for (int kk = 0; kk < KS / 4; kk++) {
-            float a2[4], b2[4], a1[2], b1[2];
-#pragma unroll
-            for (int a = 0; a < 4; a++) a2[a] = st[bA2 + 4 * kk * P1 + 16 * a];
-#pragma unroll
-            for (int b = 0; b < 4; b++) b2[b] = st[bB2 + 4 * kk * P2 + 16 * b];
-#pragma unroll
-            for (int f = 0; f < 2; f++) a1[f] = st[bA1 + 4 * kk * PX + 16 * f];
-#pragma unroll
-            for (int c = 0; c < 2; c++) b1[c] = st[bB1 + 4 * kk * P1 + 16 * c];
-            const float ah = st[bAh + 4 * kk * P2], bh = st[bBh + 4 * kk * PO], bb = st[bBb + 4 * kk * P2];
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 4; b++) acc2[a][b] = MFMA16(a2[a], b2[b], acc2[a][b]);
-#pragma unroll
-            for (int f = 0; f < 2; f++)
-#pragma unroll
-                for (int c = 0; c < 2; c++) acc1[f][c] = MFMA16(a1[f], b1[c], acc1[f][c]);
-            acch = MFMA16(ah, bh, acch);
-            accb2 = MFMA16(ones_row, bb, accb2);
-            if (wave == 0) accbh = MFMA16(ones_row, bh, accbh);
+            if (kk + 1 < KS / 4) read_ops(st, kk + 1, o[(kk + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(o[kk & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk == 1 && s0 + KS < s_end) {
+                stash(lds + (buf ^ 1) * STAGE);
+                if (s0 + 2 * KS < s_end) fetch(s0 + 2 * KS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (more) stash(lds + (buf ^ 1) * STAGE);
         __syncthreads();
         buf ^= 1;
     }
