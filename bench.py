@@ -59,10 +59,15 @@ def dense_flops_per_sample(D, hidden, A, R):
     return tot
 
 
-def measured_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE + WRITE_SIZE, separate
-    rocprofv3 runs of this script), or None when no profile of this workload is on file."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+def measured_traffic(workload, kernels):
+    """HBM bytes per launch of `kernels` (one name or several that make up a call: their sum) from the committed PMC
+    passes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 runs of this script), or None when no profile of this
+    workload is on file."""
+    if isinstance(kernels, (tuple, list)):
+        parts = [measured_traffic(workload, k) for k in kernels]
+        return None if any(x is None for x in parts) else sum(parts)
+    kernel = kernels
+    path = os.path.join(ROOT, "profiles", "r02_%s_hbm_traffic.json" % workload)
     try:
         with open(path) as fh:
             prof = json.load(fh)
@@ -420,6 +425,7 @@ def main():
     if rank == 0:
         flops_mb = (cnn_flops_per_sample(cfg["hwc"], A, cfg.get("nlstm", 0)) if image else dense_flops_per_sample(D, cfg["hidden"], A, R)) * B
         fused = (not image) and cfg["hidden"] == (64, 64)
+        fused256 = (not image) and cfg["hidden"] == (256, 128)
         if image:
             shape = "Atari-shaped rollout: %dx%dx%d uint8 obs, nature_cnn%s Categorical(%d)" % (
                 cfg["hwc"] + (" + LSTM(%d), env-sequence minibatches," % cfg["nlstm"] if cfg.get("nlstm") else "", A))
@@ -442,10 +448,13 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": ("ppo_grad = mlp_fused16_kernel + fused_finalize_kernel (minibatch gather, forward, loss, "
                                     "backward and weight gradients on fp32 MFMA)") if fused else
+                                   ("ppo_grad = gather + mlp_fused256_kernel (forward, loss, input gradients) + mlp_wgrad256_kernel "
+                                    "(all weight gradients) + slab reduction, fp32 MFMA") if fused256 else
                                    "ppo_grad = gather + layered fp32-MFMA GEMM / implicit-GEMM conv launches + loss + slab reductions",
                          "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / MFMA_F32_PEAK_TFLOPS,
-                         "traffic": measured_traffic(args.workload, "ppo2hip::mlp_fused16_kernel<5, false, 2>") if fused else None,
+                         "traffic": measured_traffic(args.workload, "ppo2hip::mlp_fused16_kernel<5, false, 2>") if fused else
+                                    measured_traffic(args.workload, ("ppo2hip::mlp_fused256_kernel", "ppo2hip::mlp_wgrad256_kernel")) if fused256 else None,
                          "flops_per_launch": flops_mb, "ms_per_launch": grad_ms},
             "gae_roofline": {"bound": "hbm", "kernel": "gae_tiled_kernel", "achieved": gae_gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": gae_gbs / HBM_PEAK_GBS, "bytes_per_launch": gae_bytes,
