@@ -129,9 +129,17 @@ int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, 
                      size_t ws_bytes, hipStream_t s, AdamFuse *adam = nullptr);
 // ---- fused forward / loss / input-gradient chain of the 256-128 two-trunk MLP (mlp_fused256.hip) ---------------
 struct Fused256Buffers {
-    const float *X;                           // gathered minibatch rows (gather_minibatch)
-    const void *ACT;
-    const float *RET, *OLDV, *NLP, *ADV;
+    // rollout arrays read in place (time-major with T, E set and an index list) or already gathered (T = 0, idx null,
+    // advantages normalised: stats null); n rows each
+    const float *obs;
+    const void *actions;
+    const float *returns, *values, *neglogpacs;
+    const void *advs;
+    int adv_f64, T, E;
+    int64_t n;
+    const int32_t *idx;
+    const double *stats;
+    float *xg;                                // [B, ob_dim] scratch for the gathered observation rows, or null when obs is gathered already
     float *H1[2], *H2[2], *DZ1[2], *DZ2[2], *DOUT[2];      // per trunk (policy, value)
     double *loss_partial;                     // mlp_fused256_loss_bytes()
     float *wslabs;                            // mlp_fused256_wgrad_bytes(): per-workgroup weight-gradient sums

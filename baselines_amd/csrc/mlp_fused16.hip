@@ -27,6 +27,7 @@
 
 #include "gemm_core.hpp"
 #include "kernels.hpp"
+#include "rowgather.hpp"
 
 namespace ppo2hip {
 
@@ -90,20 +91,6 @@ struct Fused16Args {
     float *slabs;            // [workgroup][SLAB]: the policy trunk's images, then the value trunk's
     double *loss_partial;    // [gridDim.x][kLossStride]
 };
-
-// The rollout arrays are read through buffer descriptors: 32-bit byte offsets (one register per
-// address instead of two) and hardware range checking, so a lane that reads past the last row
-// gets 0 instead of a fault and the loads need no per-lane guards.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t make_rsrc(const void *p, int64_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)(unsigned)bytes, 0x00020000);
-}
-__device__ __forceinline__ float buf_f32(rsrc_t r, unsigned byte_off) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
-}
-__device__ __forceinline__ int buf_i32(rsrc_t r, unsigned byte_off) {
-    return (int)__builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
-}
 
 // tanh of a pre-activation that arrives already multiplied by kTanhScale = 2 log2(e) (the forward copies of the
 // weights and biases carry the factor): tanh z = 1 - 2 / (2^(kTanhScale z) + 1).  v_exp_f32 and v_rcp_f32 are 1 ulp:
@@ -785,9 +772,7 @@ bool mlp_fused16_supported(const ppo2hip_policy_desc &d) {
 }
 
 bool mlp_fused16_fits(const ppo2hip_policy_desc &d, const ppo2hip_rollout &ro, int64_t B) {
-    const int64_t widest = std::max<int64_t>(std::max<int64_t>(d.ob_dim, d.ac_dim), std::max<int64_t>(d.nvalue, 2));
-    const int64_t limit = (int64_t(1) << 32) - 4096;
-    return ro.n > 0 && ro.n * widest * 4 < limit && B * 4 < limit;
+    return rollout_fits_buffer_loads(d, ro, B);
 }
 
 int mlp_fused16_grid() { return 256; }

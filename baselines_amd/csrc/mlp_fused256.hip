@@ -19,6 +19,7 @@
 // quarter with lanes along out, the backward product a column segment per lane quarter with lanes along in.
 #include "gemm_core.hpp"
 #include "kernels.hpp"
+#include "rowgather.hpp"
 
 namespace ppo2hip {
 
@@ -41,9 +42,16 @@ constexpr int kLossStride = 8 + 64;            // the partial-row format of the 
 }  // namespace f256
 
 struct Fused256Args {
-    const float *X;          // [B, D] gathered observations
-    const void *ACT;         // [B, A] float (Gaussian) or [B] int32 (Categorical)
-    const float *RET, *OLDV, *NLP, *ADV;     // [B, R], [B, R], [B], [B] (advantages already normalised)
+    // the rollout arrays as they stand (time-major with map.T / map.E set, or flat rows with map.T = 0), n rows each
+    const float *obs;        // [n, D]
+    const void *actions;     // [n, A] float (Gaussian) or [n] int32 (Categorical)
+    const float *returns, *values, *neglogpacs;      // [n, R], [n, R], [n]
+    const void *advs;        // [n] float or double, normalised here with stats (null: taken as they are)
+    int adv_f64;
+    int64_t n;
+    RowMap map;              // minibatch position -> rollout row
+    const double *stats;     // {sum, sum of squares, count} of the minibatch's advantages, or null
+    float *xg;               // [B, D] out: the observation rows in minibatch order, for the weight-gradient launch (or null)
     int64_t B;
     const float *params;
     int64_t a_w1, a_w2, a_wh, v_w1, v_w2, v_wh, logstd_off;
@@ -125,9 +133,38 @@ __global__ __launch_bounds__(f256::kThreads, 2) void mlp_fused256_kernel(Fused25
     float *const gH1 = g.H1[trunk], *const gH2 = g.H2[trunk], *const gDZ1 = g.DZ1[trunk], *const gDZ2 = g.DZ2[trunk];
     float *const gDOUT = g.DOUT[trunk];
     const int64_t ntiles = (g.B + 15) >> 4;
+    const rsrc_t r_obs = make_rsrc(g.obs, g.n * D * 4);
+    const rsrc_t r_act = make_rsrc(g.actions, gaussian ? g.n * g.A * 4 : g.n * 4);
+    const rsrc_t r_ret = make_rsrc(g.returns, g.n * g.R * 4), r_val = make_rsrc(g.values, g.n * g.R * 4);
+    const rsrc_t r_nlp = make_rsrc(g.neglogpacs, g.n * 4), r_adv = make_rsrc(g.advs, g.n * (g.adv_f64 ? 8 : 4));
+    const rsrc_t r_idx = make_rsrc(g.map.idx, g.map.idx ? g.B * 4 : 0);
+    // rollout row of this lane's sample in a tile (positions past the end read index 0: a valid row whose results are dropped)
+    auto tile_row = [&](int64_t tile) -> int {
+        const int64_t i = tile * 16 + li;
+        return g.map.row_of_sample(g.map.sample_at(r_idx, i, i < g.B));
+    };
+    // advantage normalisation constants (baselines/ppo2/common_functions.py:67)
+    double adv_mean = 0.0, adv_rstd = 1.0;
+    if (g.stats) {
+        const double cnt = g.stats[2];
+        adv_mean = g.stats[0] / cnt;
+        double var = g.stats[1] / cnt - adv_mean * adv_mean;
+        var = var > 0.0 ? var : 0.0;
+        adv_rstd = 1.0 / (sqrt(var) + 1e-8);
+    }
     const int64_t wave_global = (int64_t)wg_in_trunk * kWaves + wave, wave_stride = (int64_t)nwg_trunk * kWaves;
 
+    // Two dependent round trips stand before a tile's first product (index, then the row it names): the observation
+    // registers of the next tile are loaded while this one is worked on, and the index of the tile after that with them.
+    auto load_obs = [&](int grow, float (&x)[KQ]) {
+#pragma unroll
+        for (int q = 0; q < KQ; q++) x[q] = buf_f32(r_obs, (unsigned)grow * (unsigned)(D * 4) + 4u * (unsigned)(lk + 4 * q));   // past the row's end: the next row, or 0
+    };
+    int grow_next = tile_row(wave_global), grow_after = tile_row(wave_global + wave_stride);
+    float xn[KQ];
+    load_obs(grow_next, xn);
     for (int64_t tile = wave_global; tile < ntiles; tile += wave_stride) {
+        const int grow = grow_next;
 #pragma unroll
         for (int r = 0; r < 4; r++) asm volatile("" : "+v"(a_fw[r]), "+v"(a_bw[r]));
         asm volatile("" : "+v"(a_l1), "+v"(a_hf), "+v"(a_hb), "+v"(a_b));
@@ -140,7 +177,8 @@ __global__ __launch_bounds__(f256::kThreads, 2) void mlp_fused256_kernel(Fused25
 #pragma unroll
         for (int q = 0; q < KQ; q++) {
             const int k = lk + 4 * q;
-            xr[q] = k < D ? g.X[row * D + k] : (k == D ? 1.f : 0.f);
+            xr[q] = k < D ? xn[q] : (k == D ? 1.f : 0.f);
+            if (g.xg && !is_value && live && k < D) g.xg[srow * D + k] = xn[q];
         }
         // ---- layer 1 ----------------------------------------------------------------------------------------
         f32x4 h1[HB1];
@@ -166,6 +204,9 @@ __global__ __launch_bounds__(f256::kThreads, 2) void mlp_fused256_kernel(Fused25
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        grow_next = grow_after;
+        load_obs(grow_next, xn);
+        grow_after = tile_row(tile + 2 * wave_stride);
 #pragma unroll
         for (int mb = 0; mb < HB1; mb++) {
 #pragma unroll
@@ -207,21 +248,28 @@ __global__ __launch_bounds__(f256::kThreads, 2) void mlp_fused256_kernel(Fused25
         float adv = 0.f, oldnlp = 0.f, act[4] = {0.f, 0.f, 0.f, 0.f}, ret[4] = {0.f, 0.f, 0.f, 0.f}, oldv[4] = {0.f, 0.f, 0.f, 0.f};
         int act_i = 0;
         if (!is_value) {
-            adv = g.ADV[row];
-            oldnlp = g.NLP[row];
+            double a;
+            if (g.adv_f64) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(r_adv, (int)((unsigned)grow * 8u), 0, 0);
+                a = __longlong_as_double((long long)(((unsigned long long)v[1] << 32) | v[0]));
+            } else {
+                a = (double)buf_f32(r_adv, (unsigned)grow * 4u);
+            }
+            adv = (float)((a - adv_mean) * adv_rstd);
+            oldnlp = buf_f32(r_nlp, (unsigned)grow * 4u);
             if (gaussian) {
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    if (4 * lk + r < g.A) act[r] = ((const float *)g.ACT)[row * g.A + 4 * lk + r];
+                    if (4 * lk + r < g.A) act[r] = buf_f32(r_act, ((unsigned)grow * (unsigned)g.A + 4u * lk + r) * 4u);
             } else {
-                act_i = ((const int *)g.ACT)[row];
+                act_i = buf_i32(r_act, (unsigned)grow * 4u);
             }
         } else {
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 if (4 * lk + r < g.R) {
-                    ret[r] = g.RET[row * g.R + 4 * lk + r];
-                    oldv[r] = g.OLDV[row * g.R + 4 * lk + r];
+                    ret[r] = buf_f32(r_ret, ((unsigned)grow * (unsigned)g.R + 4u * lk + r) * 4u);
+                    oldv[r] = buf_f32(r_val, ((unsigned)grow * (unsigned)g.R + 4u * lk + r) * 4u);
                 }
         }
 
@@ -455,7 +503,7 @@ constexpr int kSlabsPerTrunk = 128;
 }  // namespace w256
 
 struct Wgrad256Args {
-    const float *X;
+    const float *X;          // [B, D] observation rows in minibatch order
     const float *H1[2], *H2[2], *DZ1[2], *DZ2[2], *DOUT[2];
     int64_t B, rows_per_wg;
     int D, A, R;
@@ -655,7 +703,9 @@ int mlp_fused256_wgrad(const ppo2hip_policy_desc &d, const FusedOffsets &fo, con
                        hipStream_t s) {
     using namespace w256;
     Wgrad256Args g;
-    g.X = b.X;
+    // observation rows in minibatch order: the chain launch's gathered copy, or the rows as they stand when the caller
+    // gathered them (random 68-byte rows cost this kernel's slab pipeline 80 us per minibatch when it gathered them itself)
+    g.X = b.xg ? b.xg : b.obs;
     for (int t = 0; t < 2; t++) { g.H1[t] = b.H1[t]; g.H2[t] = b.H2[t]; g.DZ1[t] = b.DZ1[t]; g.DZ2[t] = b.DZ2[t]; g.DOUT[t] = b.DOUT[t]; }
     g.B = B;
     g.rows_per_wg = (int64_t)ceil_div(ceil_div(B > 0 ? B : 1, (int64_t)kSlabsPerTrunk), (int64_t)KS) * KS;
@@ -686,7 +736,9 @@ int mlp_fused256_chain(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc
                        const Fused256Buffers &b, int64_t B, float cliprange, double inv_count, float *losses, float *dlogstd,
                        hipStream_t s) {
     Fused256Args g;
-    g.X = b.X; g.ACT = b.ACT; g.RET = b.RET; g.OLDV = b.OLDV; g.NLP = b.NLP; g.ADV = b.ADV; g.B = B; g.params = params;
+    g.obs = b.obs; g.actions = b.actions; g.returns = b.returns; g.values = b.values; g.neglogpacs = b.neglogpacs;
+    g.advs = b.advs; g.adv_f64 = b.adv_f64; g.n = b.n; g.map = make_row_map(b.idx, B, b.T, b.E); g.stats = b.stats;
+    g.xg = b.xg; g.B = B; g.params = params;
     g.a_w1 = fo.a_w1; g.a_w2 = fo.a_w2; g.a_wh = fo.a_wh; g.v_w1 = fo.v_w1; g.v_w2 = fo.v_w2; g.v_wh = fo.v_wh; g.logstd_off = fo.logstd;
     g.D = d.ob_dim; g.A = d.ac_dim; g.R = d.nvalue; g.dist = d.dist; g.upstream = lc.upstream;
     g.cliprange = cliprange; g.ent_coef = lc.ent_coef; g.vf_coef = lc.upstream ? lc.vf_coef : 1.0f; g.inv_count = (float)inv_count;

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "rowgather.hpp"
 
 namespace ppo2hip {
 
@@ -242,32 +243,37 @@ static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
         return mlp_fused_grad(d, lc, p, fo, ro, idx, B, stats, cliprange, inv_count, grads, losses, w.fused,
                               w.fused_bytes, s);
     }
-    GatherArgs g;
-    g.ro = &ro; g.idx = idx; g.B = B; g.ob_bytes = (int64_t)D * 4; g.ac_bytes = gauss ? (int64_t)A * 4 : 4;
-    g.nvalue = R; g.stats = stats; g.obs = w.X; g.actions = w.ACT; g.returns = w.RET; g.values = w.OLDV;
-    g.neglogpacs = w.NLP; g.advs = w.ADV; g.masks = nullptr;
     int rc;
-    if ((rc = gather_minibatch(g, s))) return rc;
     if (path == 256) {
-        // forward, loss and both input-gradient products of both trunks in one launch; the weight gradients from its outputs
+        // forward, loss and both input-gradient products of both trunks in one launch, then every weight gradient in
+        // another; both read the minibatch rows straight out of the rollout where 32-bit offsets reach them
         FusedOffsets fo{L.off("pi_fc1/w"), L.off("pi_fc2/w"), L.off("pi/w"), L.off("vf_fc1/w"), L.off("vf_fc2/w"),
                         L.off("vf/w"), gauss ? L.off("logstd") : 0};
         Fused256Buffers fb;
-        fb.X = w.X; fb.ACT = w.ACT; fb.RET = w.RET; fb.OLDV = w.OLDV; fb.NLP = w.NLP; fb.ADV = w.ADV;
+        if (rollout_fits_buffer_loads(d, ro, B) && !getenv("PPO2HIP_F256_GATHER")) {
+            fb.obs = (const float *)ro.obs; fb.actions = ro.actions; fb.returns = ro.returns; fb.values = ro.values;
+            fb.neglogpacs = ro.neglogpacs; fb.advs = ro.advs; fb.adv_f64 = ro.adv_f64; fb.T = ro.T; fb.E = ro.E; fb.n = ro.n;
+            fb.idx = idx; fb.stats = stats; fb.xg = w.X;
+        } else {
+            GatherArgs g;
+            g.ro = &ro; g.idx = idx; g.B = B; g.ob_bytes = (int64_t)D * 4; g.ac_bytes = gauss ? (int64_t)A * 4 : 4;
+            g.nvalue = R; g.stats = stats; g.obs = w.X; g.actions = w.ACT; g.returns = w.RET; g.values = w.OLDV;
+            g.neglogpacs = w.NLP; g.advs = w.ADV; g.masks = nullptr;
+            if ((rc = gather_minibatch(g, s))) return rc;
+            fb.obs = w.X; fb.actions = w.ACT; fb.returns = w.RET; fb.values = w.OLDV; fb.neglogpacs = w.NLP; fb.advs = w.ADV;
+            fb.adv_f64 = 0; fb.T = 0; fb.E = 0; fb.n = B; fb.idx = nullptr; fb.stats = nullptr; fb.xg = nullptr;
+        }
         fb.H1[0] = w.H1a; fb.H2[0] = w.H2a; fb.DZ1[0] = w.dZ1; fb.DZ2[0] = w.dZ2; fb.DOUT[0] = w.dPI;
         fb.H1[1] = w.H1v; fb.H2[1] = w.H2v; fb.DZ1[1] = w.dZ1v; fb.DZ2[1] = w.dZ2v; fb.DOUT[1] = w.dVF;
         fb.loss_partial = w.loss256; fb.wslabs = w.wslabs256;
         if ((rc = mlp_fused256_chain(d, lc, p, fo, fb, B, cliprange, inv_count, losses, gauss ? grads + L.off("logstd") : nullptr, s))) return rc;
-        if (!getenv("PPO2HIP_F256_GEMM_WGRAD")) return mlp_fused256_wgrad(d, fo, fb, B, grads, s);
-        for (int t = 0; t < 2; t++) {
-            const int N = t ? R : A;
-            const int64_t o1 = L.off(t ? "vf_fc1/w" : "pi_fc1/w"), o2 = L.off(t ? "vf_fc2/w" : "pi_fc2/w"), oh = L.off(t ? "vf/w" : "pi/w");
-            if ((rc = fc_wgrad_into(fb.H2[t], h2, fb.DOUT[t], N, B, h2, N, w, grads + oh, s))) return rc;
-            if ((rc = fc_wgrad_into(fb.H1[t], h1, fb.DZ2[t], h2, B, h1, h2, w, grads + o2, s))) return rc;
-            if ((rc = fc_wgrad_into(w.X, D, fb.DZ1[t], h1, B, D, h1, w, grads + o1, s))) return rc;
-        }
-        return 0;
+        return mlp_fused256_wgrad(d, fo, fb, B, grads, s);
     }
+    GatherArgs g;
+    g.ro = &ro; g.idx = idx; g.B = B; g.ob_bytes = (int64_t)D * 4; g.ac_bytes = gauss ? (int64_t)A * 4 : 4;
+    g.nvalue = R; g.stats = stats; g.obs = w.X; g.actions = w.ACT; g.returns = w.RET; g.values = w.OLDV;
+    g.neglogpacs = w.NLP; g.advs = w.ADV; g.masks = nullptr;
+    if ((rc = gather_minibatch(g, s))) return rc;
     if ((rc = mlp_forward(d, L, p, w, B, w.PI, w.VF, s))) return rc;
     LossArgs la;
     la.dist = d.dist; la.ac_dim = A; la.nvalue = R; la.B = B; la.pi = w.PI;
