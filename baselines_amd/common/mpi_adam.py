@@ -8,7 +8,10 @@ Transports:
            GPU per rank.  ``torch.distributed`` is only the control plane that hands rank 0's unique id round.
   "host" — ``torch.distributed`` itself; with the gloo backend device tensors are staged through the host (test
            rigs in which several ranks share one GPU, where RCCL cannot run).
-  "auto" — "rccl" when torch.distributed runs on nccl (= RCCL: every rank has its GPU), else "host".
+  "torch" — ``torch.distributed``'s own RCCL process group on device tensors (one Python call per collective); what
+           "rccl" falls back to, on every rank together, when some rank cannot join the library's communicator.
+  "auto" — "rccl" when torch.distributed runs on nccl (= RCCL: every rank has its GPU), else "host";
+           ``PPO2HIP_DP_TRANSPORT`` overrides the choice.
 
 Two sharding modes (envs shard by index in both, so GAE needs no communication):
   "mpi"    — the reference's semantics: every rank shuffles and normalises its own shard,
@@ -27,16 +30,17 @@ class DataParallel:
     def __init__(self, mode="mpi", group=None, transport="auto"):
         if mode not in ("mpi", "global"):
             raise ValueError("mode must be 'mpi' or 'global'")
-        if transport not in ("auto", "rccl", "host"):
-            raise ValueError("transport must be 'auto', 'rccl' or 'host'")
+        if transport not in ("auto", "rccl", "host", "torch"):
+            raise ValueError("transport must be 'auto', 'rccl', 'host' or 'torch'")
         self.mode = mode
         self.group = group
         self.size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         backend = dist.get_backend(group) if dist.is_initialized() else ""
         self._gloo = backend == "gloo"
+        import os
         if transport == "auto":
-            transport = "rccl" if "nccl" in backend else "host"
+            transport = os.environ.get("PPO2HIP_DP_TRANSPORT") or ("rccl" if "nccl" in backend else "host")
         self.transport = transport
         self._native = None
         self._pending_checks = []
@@ -58,7 +62,22 @@ class DataParallel:
             box = [hip.NativeComm.unique_id() if self.rank == 0 else None]
             dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                                        group=self.group)
-            self._native = hip.NativeComm(box[0], self.rank, self.size)
+            comm, err = None, None
+            try:
+                comm = hip.NativeComm(box[0], self.rank, self.size)
+            except Exception as e:          # every rank must take the same transport: agree before using it
+                err = e
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 0:
+                # some rank could not join the library's communicator: all ranks carry on over torch.distributed's own
+                # RCCL process group (same collectives, one Python call per all-reduce)
+                import sys
+                print("baselines_amd: library communicator unavailable on rank %d (%s); using torch.distributed"
+                      % (self.rank, err), file=sys.stderr)
+                self.transport = "torch"
+                return None
+            self._native = comm
         return self._native
 
     def _staged(self, t):
