@@ -2,10 +2,10 @@
 // per-minibatch normalisation.  All reductions are fixed-shape (per-block partials, then
 // a single ordered pass), so results are reproducible run to run.
 #include "common.hpp"
+#include "kernels.hpp"
 
 namespace ppo2hip {
 
-constexpr int kMaxR = 8;
 constexpr int kAdvsBlocks = 512;   // partial-sum rows of compute_advs pass 1
 constexpr int kStatChunks = 128;   // partial-sum chunks per minibatch of adv_stats
 struct RVec { double v[kMaxR]; };
@@ -66,7 +66,8 @@ __global__ void advs_scalar_kernel(const float *__restrict__ advs_ori, const dou
 // Partial sums of a and a^2 over chunk c of minibatch j (grid = kStatChunks x nmb).
 template <class A>
 __global__ void adv_stats_partial_kernel(const A *__restrict__ advs, const int32_t *__restrict__ idx,
-                                         int64_t B, int T, int E, double *__restrict__ partial) {
+                                         int64_t B, int T, int E, double *__restrict__ partial, int64_t limit,
+                                         unsigned *fault) {
     __shared__ double red[17];
     const int j = blockIdx.y;
     const int64_t per = (B + gridDim.x - 1) / gridDim.x;
@@ -81,7 +82,7 @@ __global__ void adv_stats_partial_kernel(const A *__restrict__ advs, const int32
         for (int u = 0; u < U; u++) {
             const int64_t i = base + (int64_t)u * blockDim.x + threadIdx.x;
             const int64_t row = (int64_t)j * B + (i < hi ? i : lo);
-            smp[u] = idx ? (int64_t)idx[row] : row;
+            smp[u] = idx ? checked_sample(idx[row], limit, fault) : row;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) a[u] = (double)advs[tm_offset(smp[u], T, E)];
@@ -165,10 +166,14 @@ extern "C" int ppo2hip_adv_stats(const void *advs, int adv_f64, const int32_t *i
     double *partial = (double *)workspace;
     int nchunks = (int)(ceil_div(B, 1024) < kStatChunks ? ceil_div(B, 1024) : kStatChunks);
     dim3 grid(nchunks, nmb);
+    unsigned *fault = fault_word();
+    if (!fault) return PPO2HIP_EINVAL;
+    // time-major arrays say how many samples there are; for flat rows (T = 0) the caller's list is taken as it is
+    const int64_t limit = T > 0 ? (int64_t)T * E : (int64_t)1 << 62;
     if (adv_f64)
-        hipLaunchKernelGGL(adv_stats_partial_kernel<double>, grid, dim3(256), 0, s, (const double *)advs, idx, B, T, E, partial);
+        hipLaunchKernelGGL(adv_stats_partial_kernel<double>, grid, dim3(256), 0, s, (const double *)advs, idx, B, T, E, partial, limit, fault);
     else
-        hipLaunchKernelGGL(adv_stats_partial_kernel<float>, grid, dim3(256), 0, s, (const float *)advs, idx, B, T, E, partial);
+        hipLaunchKernelGGL(adv_stats_partial_kernel<float>, grid, dim3(256), 0, s, (const float *)advs, idx, B, T, E, partial, limit, fault);
     int rc = check_launch("adv_stats_partial_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(adv_stats_final_kernel, dim3((unsigned)nmb), dim3(64), 0, s, partial, nchunks, B, nmb, stats);

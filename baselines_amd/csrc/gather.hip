@@ -2,27 +2,51 @@
 // baselines/ppo2/ppo2.py:117, read straight out of the time-major rollout (the sf01
 // flatten never materialises), fused with the advantage normalisation of
 // baselines/ppo2/common_functions.py:67.
+#include <mutex>
+
 #include "kernels.hpp"
 
 namespace ppo2hip {
 
+static __device__ unsigned g_fault_bits[4];
+static unsigned *g_fault_ptr[64];
+static std::mutex g_fault_mu;
+
+unsigned *fault_word() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        set_error("fault word: no current device");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_fault_mu);
+    if (!g_fault_ptr[dev]) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fault_bits)) != hipSuccess || !p) {
+            set_error("fault word: no device address for the symbol");
+            return nullptr;
+        }
+        g_fault_ptr[dev] = (unsigned *)p;
+    }
+    return g_fault_ptr[dev];
+}
+
 // one 4-byte (or 1-byte) word of one observation row per loop trip
 template <class W>
 __global__ void gather_rows_kernel(const W *__restrict__ src, const int32_t *__restrict__ idx, int64_t B,
-                                   int64_t row_words, int T, int E, W *__restrict__ dst) {
+                                   int64_t row_words, int T, int E, W *__restrict__ dst, int64_t limit, unsigned *fault) {
     const int64_t total = B * row_words;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = g / row_words, w = g - i * row_words;
-        const int64_t smp = idx ? (int64_t)idx[i] : i;
+        const int64_t smp = idx ? checked_sample(idx[i], limit, fault) : i;
         dst[g] = src[tm_offset(smp, T, E) * row_words + w];
     }
 }
 
 // 16-byte words for big, aligned rows (image observations)
 __global__ void gather_rows16_kernel(const uint4 *__restrict__ src, const int32_t *__restrict__ idx, int64_t B,
-                                     int64_t row_words, int T, int E, uint4 *__restrict__ dst) {
+                                     int64_t row_words, int T, int E, uint4 *__restrict__ dst, int64_t limit, unsigned *fault) {
     const int64_t i = blockIdx.x;
-    const int64_t smp = idx ? (int64_t)idx[i] : i;
+    const int64_t smp = idx ? checked_sample(idx[i], limit, fault) : i;
     const uint4 *s = src + tm_offset(smp, T, E) * row_words;
     uint4 *d = dst + i * row_words;
     for (int64_t w = threadIdx.x; w < row_words; w += blockDim.x) d[w] = s[w];
@@ -40,10 +64,10 @@ struct SmallGather {
     uint32_t *o_actions;
 };
 
-__global__ void gather_small_kernel(SmallGather g, const int32_t *__restrict__ idx, int64_t B) {
+__global__ void gather_small_kernel(SmallGather g, const int32_t *__restrict__ idx, int64_t B, int64_t limit, unsigned *fault) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
-    const int64_t smp = idx ? (int64_t)idx[i] : i;
+    const int64_t smp = idx ? checked_sample(idx[i], limit, fault) : i;
     const int64_t r = tm_offset(smp, g.T, g.E);
     for (int k = 0; k < g.nvalue; k++) {
         g.o_returns[i * g.nvalue + k] = g.returns[r * g.nvalue + k];
@@ -77,21 +101,24 @@ int gather_minibatch(const GatherArgs &g, hipStream_t s) {
     const ppo2hip_rollout *ro = g.ro;
     const int64_t B = g.B;
     if (B <= 0) return 0;
+    unsigned *fault = fault_word();
+    if (!fault) return PPO2HIP_EINVAL;
+    const int64_t limit = rollout_samples(*ro);
     // observations
     const bool a16 = (g.ob_bytes % 16 == 0) && ((uintptr_t)ro->obs % 16 == 0) && ((uintptr_t)g.obs % 16 == 0) && g.ob_bytes >= 1024;
     if (a16) {
         hipLaunchKernelGGL(gather_rows16_kernel, dim3((unsigned)B), dim3(256), 0, s, (const uint4 *)ro->obs, g.idx, B,
-                           g.ob_bytes / 16, ro->T, ro->E, (uint4 *)g.obs);
+                           g.ob_bytes / 16, ro->T, ro->E, (uint4 *)g.obs, limit, fault);
     } else if (g.ob_bytes % 4 == 0) {
         const int64_t total = B * (g.ob_bytes / 4);
         const int64_t nb = ceil_div(total, 256) < 65536 ? ceil_div(total, 256) : 65536;
         hipLaunchKernelGGL(gather_rows_kernel<uint32_t>, dim3((unsigned)nb), dim3(256), 0, s, (const uint32_t *)ro->obs,
-                           g.idx, B, g.ob_bytes / 4, ro->T, ro->E, (uint32_t *)g.obs);
+                           g.idx, B, g.ob_bytes / 4, ro->T, ro->E, (uint32_t *)g.obs, limit, fault);
     } else {
         const int64_t total = B * g.ob_bytes;
         const int64_t nb = ceil_div(total, 256) < 65536 ? ceil_div(total, 256) : 65536;
         hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3((unsigned)nb), dim3(256), 0, s, (const uint8_t *)ro->obs,
-                           g.idx, B, g.ob_bytes, ro->T, ro->E, (uint8_t *)g.obs);
+                           g.idx, B, g.ob_bytes, ro->T, ro->E, (uint8_t *)g.obs, limit, fault);
     }
     int rc = check_launch("gather_rows");
     if (rc) return rc;
@@ -101,7 +128,7 @@ int gather_minibatch(const GatherArgs &g, hipStream_t s) {
     sg.nvalue = g.nvalue; sg.ac_words = (int)(g.ac_bytes / 4); sg.stats = g.stats;
     sg.o_returns = g.returns; sg.o_values = g.values; sg.o_neglogpacs = g.neglogpacs; sg.o_advs = g.advs;
     sg.o_masks = (g.masks && ro->masks) ? g.masks : nullptr; sg.o_actions = (uint32_t *)g.actions;
-    hipLaunchKernelGGL(gather_small_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, s, sg, g.idx, B);
+    hipLaunchKernelGGL(gather_small_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, s, sg, g.idx, B, limit, fault);
     return check_launch("gather_small");
 }
 
@@ -122,11 +149,10 @@ int gather_states(const float *states, const int32_t *envs, int nenv_mb, int wid
 // ---------------------------------------------------------------------------------------
 namespace ppo2hip {
 __global__ void compose_kernel(const int32_t *__restrict__ prev, const int32_t *__restrict__ sigma,
-                               int32_t *__restrict__ out, int64_t n) {
+                               int32_t *__restrict__ out, int64_t n, unsigned *fault) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const int32_t s = sigma[k];
-    out[k] = (s >= 0 && s < n) ? prev[s] : 0;
+    out[k] = prev[checked_sample(sigma[k], n, fault, kFaultComposeRange)];
 }
 }  // namespace ppo2hip
 
@@ -135,7 +161,23 @@ extern "C" int ppo2hip_compose_i32(const int32_t *prev, const int32_t *sigma, in
     PPO2HIP_REQUIRE(n >= 0 && n <= 0x7fffffffll, "compose: bad n=%lld", (long long)n);
     if (n == 0) return PPO2HIP_OK;
     PPO2HIP_REQUIRE(prev && sigma && out && out != prev && out != sigma, "compose: null or aliased pointer");
+    unsigned *fault = fault_word();
+    if (!fault) return PPO2HIP_EINVAL;
     hipLaunchKernelGGL(compose_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, prev, sigma,
-                       out, n);
+                       out, n, fault);
     return check_launch("compose_kernel");
+}
+
+extern "C" int ppo2hip_take_faults(uint32_t *bits, void *stream) {
+    using namespace ppo2hip;
+    PPO2HIP_REQUIRE(bits != nullptr, "take_faults: null pointer");
+    unsigned *fault = fault_word();
+    if (!fault) return PPO2HIP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t host = 0;
+    PPO2HIP_CHECK_HIP(hipMemcpyAsync(&host, fault, sizeof(host), hipMemcpyDeviceToHost, s));
+    PPO2HIP_CHECK_HIP(hipStreamSynchronize(s));
+    if (host) PPO2HIP_CHECK_HIP(hipMemsetAsync(fault, 0, sizeof(host), s));
+    *bits = host;
+    return PPO2HIP_OK;
 }

@@ -48,6 +48,12 @@ int conv_wgrad_max_slabs(const ConvShape &c);
 int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, const ConvShape &c, hipStream_t s);
 
 // ---- gather (gather.hip) ---------------------------------------------------------------
+// device address of this GPU's fault word (a static device array of the library; symbol lookup on the first call per
+// device, no allocation); null with an error set when the lookup fails
+unsigned *fault_word();
+// how many samples an index into a rollout may name
+inline int64_t rollout_samples(const ppo2hip_rollout &ro) { return ro.T > 0 ? (int64_t)ro.T * ro.E : ro.n; }
+
 struct GatherArgs {
     const ppo2hip_rollout *ro;
     const int32_t *idx;

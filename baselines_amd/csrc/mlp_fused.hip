@@ -41,6 +41,8 @@ struct FusedArgs {
     const int32_t *idx;
     int64_t B;
     const double *stats;
+    int64_t nsamples;        // sample numbers the index list may name
+    unsigned *fault;         // the device's fault word
     // network
     const float *params;
     TrunkOffsets actor, value;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mlp_fused_kernel(FusedArgs g
     for (int64_t tile = wave_global; tile < ntiles; tile += wave_stride) {
         const int64_t i = tile * 32 + li;
         const bool live = i < g.B;
-        const int64_t smp = live ? (g.idx ? (int64_t)g.idx[i] : i) : 0;
+        const int64_t smp = live ? (g.idx ? checked_sample(g.idx[i], g.nsamples, g.fault) : i) : 0;
         const int64_t row = tm_offset(smp, g.T, g.E);
 
         // ---- gather the 32 observation rows into the x tile (+ ones feature at column D) ----
@@ -749,6 +751,8 @@ int mlp_fused_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, co
     g.obs = (const float *)ro.obs; g.actions = ro.actions; g.returns = ro.returns; g.values = ro.values;
     g.neglogpacs = ro.neglogpacs; g.advs = ro.advs; g.adv_f64 = ro.adv_f64; g.T = ro.T; g.E = ro.E;
     g.idx = idx; g.B = B; g.stats = stats; g.params = params;
+    g.nsamples = rollout_samples(ro); g.fault = fault_word();
+    if (!g.fault) return PPO2HIP_EINVAL;
     g.actor = TrunkOffsets{fo.a_w1, fo.a_w2, fo.a_wh};
     g.value = TrunkOffsets{fo.v_w1, fo.v_w2, fo.v_wh};
     g.logstd_off = fo.logstd; g.D = d.ob_dim; g.A = d.ac_dim; g.R = d.nvalue; g.dist = d.dist;

@@ -77,6 +77,8 @@ struct Fused16Args {
     const void *advs;
     int adv_f64, T, E;
     int64_t n;               // rows in every rollout array
+    unsigned nsamples;       // sample numbers the index list may name (T E, or n for flat arrays)
+    unsigned *fault;         // the device's fault word
     const int32_t *idx;
     int64_t B;
     const double *stats;
@@ -161,8 +163,15 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
     auto tile_row = [&](int64_t tile) -> int {
         const int64_t i = tile * 16 + li;
         int smp;
-        if (g.idx) smp = buf_i32(r_idx, (unsigned)(i < g.B ? i : g.B) * 4u);
-        else smp = i < g.B ? (int)i : 0;
+        if (g.idx) {
+            smp = buf_i32(r_idx, (unsigned)(i < g.B ? i : g.B) * 4u);
+            if ((unsigned)smp >= g.nsamples) {       // a stale list: reported, not followed
+                atomicOr(g.fault, kFaultIndexRange);
+                smp = 0;
+            }
+        } else {
+            smp = i < g.B ? (int)i : 0;
+        }
         if (g.T == 0) return smp;
         // env = smp / T by multiplication (Granlund-Montgomery round-up form; magic and shifts from the host)
         const unsigned n = (unsigned)smp, t = __umulhi(g.div_magic, n);
@@ -823,6 +832,9 @@ int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, 
     g.fin_barrier = (unsigned *)extra;
     g.obs = (const float *)ro.obs; g.actions = ro.actions; g.returns = ro.returns; g.values = ro.values;
     g.neglogpacs = ro.neglogpacs; g.advs = ro.advs; g.adv_f64 = ro.adv_f64; g.T = ro.T; g.E = ro.E; g.n = ro.n;
+    { const int64_t ns = rollout_samples(ro); g.nsamples = (unsigned)(ns < 0x7fffffffll ? ns : 0x7fffffffll); }
+    g.fault = fault_word();
+    if (!g.fault) return PPO2HIP_EINVAL;
     g.idx = idx; g.B = B; g.stats = stats; g.params = params;
     g.a_w1 = fo.a_w1; g.a_w2 = fo.a_w2; g.a_wh = fo.a_wh; g.v_w1 = fo.v_w1; g.v_w2 = fo.v_w2; g.v_wh = fo.v_wh;
     g.logstd_off = fo.logstd; g.D = d.ob_dim; g.A = d.ac_dim; g.R = d.nvalue; g.dist = d.dist;

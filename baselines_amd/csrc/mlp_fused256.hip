@@ -737,7 +737,8 @@ int mlp_fused256_chain(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc
                        hipStream_t s) {
     Fused256Args g;
     g.obs = b.obs; g.actions = b.actions; g.returns = b.returns; g.values = b.values; g.neglogpacs = b.neglogpacs;
-    g.advs = b.advs; g.adv_f64 = b.adv_f64; g.n = b.n; g.map = make_row_map(b.idx, B, b.T, b.E); g.stats = b.stats;
+    g.advs = b.advs; g.adv_f64 = b.adv_f64; g.n = b.n; g.map = make_row_map(b.idx, B, b.T, b.E, b.T > 0 ? (int64_t)b.T * b.E : b.n, fault_word()); g.stats = b.stats;
+    if (!g.map.fault) return PPO2HIP_EINVAL;
     g.xg = b.xg; g.B = B; g.params = params;
     g.a_w1 = fo.a_w1; g.a_w2 = fo.a_w2; g.a_wh = fo.a_wh; g.v_w1 = fo.v_w1; g.v_w2 = fo.v_w2; g.v_wh = fo.v_wh; g.logstd_off = fo.logstd;
     g.D = d.ob_dim; g.A = d.ac_dim; g.R = d.nvalue; g.dist = d.dist; g.upstream = lc.upstream;

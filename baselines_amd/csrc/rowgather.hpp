@@ -30,6 +30,8 @@ struct RowMap {
     int T, E;
     unsigned magic;
     int sh1, sh2;
+    unsigned nsamples;       // sample numbers a list may name: T E, or the row count of flat arrays
+    unsigned *fault;         // the device's fault word (checked_sample)
     // branch-free on purpose: a branch in the middle of a software-pipelined loop makes the compiler drain its loads there
     __device__ __forceinline__ int row_of_sample(int smp) const {
         const unsigned n = (unsigned)smp, t = __umulhi(magic, n);
@@ -40,14 +42,19 @@ struct RowMap {
     // sample number of minibatch position i (pos_ok: i is inside the caller's range); r_idx covers idx[0 .. B) (size 0
     // without a list: the load returns 0 and i itself is taken)
     __device__ __forceinline__ int sample_at(rsrc_t r_idx, int64_t i, bool pos_ok) const {
-        const int listed = buf_i32(r_idx, (unsigned)(pos_ok ? i : B) * 4u);
+        int listed = buf_i32(r_idx, (unsigned)(pos_ok ? i : B) * 4u);
+        if ((unsigned)listed >= nsamples) {      // a stale list: reported, not followed (never taken on a good one)
+            atomicOr(fault, kFaultIndexRange);
+            listed = 0;
+        }
         const int self = pos_ok ? (int)i : 0;
         return idx ? listed : self;
     }
 };
-inline RowMap make_row_map(const int32_t *idx, int64_t B, int T, int E) {
+inline RowMap make_row_map(const int32_t *idx, int64_t B, int T, int E, int64_t nsamples, unsigned *fault) {
     RowMap m;
     m.idx = idx; m.B = B; m.T = T; m.E = E;
+    m.nsamples = (unsigned)(nsamples < 0x7fffffffll ? nsamples : 0x7fffffffll); m.fault = fault;
     const unsigned t = T > 0 ? (unsigned)T : 1u;
     int sh = 0;
     while ((1ull << sh) < t) sh++;

@@ -392,6 +392,23 @@ def compose(prev, sigma, out):
     return out
 
 
+FAULT_INDEX_RANGE, FAULT_COMPOSE_RANGE = 1, 2
+
+
+def take_faults(raise_on_fault=True):
+    """Waits for the stream and collects (and clears) this GPU's fault word: which caller-supplied index lists used since
+    the last call named a sample that does not exist (the kernels replaced those entries by sample 0 instead of
+    reading out of bounds).  NumPy raises IndexError where the reference indexes with such a list
+    (baselines/ppo2/ppo2.py:117); this raises Ppo2HipError(EINVAL)."""
+    bits = ctypes.c_uint32(0)
+    check(lib.ppo2hip_take_faults(ctypes.byref(bits), _stream()), "take_faults")
+    if bits.value and raise_on_fault:
+        what = [name for bit, name in ((FAULT_INDEX_RANGE, "a minibatch index list"), (FAULT_COMPOSE_RANGE, "a permutation handed to compose"))
+                if bits.value & bit]
+        raise _lib.Ppo2HipError("index check failed (code %d): out-of-range entry in %s; results since the last check are invalid" % (_lib.EINVAL, " and ".join(what)))
+    return bits.value
+
+
 # --------------------------------------------------------------------------------------
 # policy arena, forward, gradient, optimiser
 # --------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ from collections import deque
 
 import numpy as np
 
-from .. import logger
+from .. import hip, logger
 from .common_functions import *   # noqa: F401,F403  (Model, Runner, sf01, constfn, compute_advs, REWARD_NUM)
 from .common_functions import Model, Runner, compute_advs, constfn
 
@@ -105,6 +105,7 @@ def learn(*, policy, env, nsteps, total_timesteps, ent_coef, lr,
         if device_path:
             lossvals = model.train_on_rollout(float(lrnow), float(cliprangenow), ro, noptepochs, nbatch_train,
                                                more_updates=update < nupdates).cpu().numpy()
+            hip.take_faults()                     # a stale index list raises here, as NumPy's fancy indexing would
         else:
             # the reference's host loop (:109-137): shuffle, fancy-index gather, Model.train per minibatch
             advs_host = sf01_host(ro.advs)

@@ -183,6 +183,17 @@ int ppo2hip_perm_wait_all(ppo2hip_perm *p);
 /* DEVICE pointers: out[k] = prev[sigma[k]] for k < n (out must not alias prev or sigma). */
 int ppo2hip_compose_i32(const int32_t *prev, const int32_t *sigma, int32_t *out, int64_t n, void *stream);
 
+/* Index lists are the caller's (the reference indexes NumPy arrays with them, baselines/ppo2/ppo2.py:117, and NumPy
+ * raises IndexError on a bad one).  Every kernel that follows a list checks each entry where it uses it: an entry outside
+ * [0, number of samples) is replaced by sample 0 and raises a bit of a per-GPU fault word instead of reading out of
+ * bounds.  This call waits for `stream`, returns the word in *bits and clears it: 0 = every list used since the last
+ * call was in range; PPO2HIP_FAULT_INDEX_RANGE = a minibatch index list (ppo_grad, ppo_epoch, adv_stats with T > 0);
+ * PPO2HIP_FAULT_COMPOSE_RANGE = a sigma entry of ppo2hip_compose_i32.  Results computed from a flagged list are
+ * meaningless; the Python layer raises Ppo2HipError(EINVAL) when it collects a non-zero word with the losses. */
+#define PPO2HIP_FAULT_INDEX_RANGE 1u
+#define PPO2HIP_FAULT_COMPOSE_RANGE 2u
+int ppo2hip_take_faults(uint32_t *bits, void *stream);
+
 /* ------------------------------------------------------------------------
  * Policy description and parameter arena
  * ---------------------------------------------------------------------- */
