@@ -185,6 +185,14 @@ int lstm_gates_bwd(float *gates, int64_t z_stride, const float *c, const float *
                    int64_t s_stride, const float *dhm_parts, int nparts, float *dcm_carry, const uint8_t *mask_next,
                    int64_t mask_stride, int nenv, int nh, hipStream_t s);
 
+// one launch per step and direction (product + element-wise half) for the widths lstm_step_fused_width() names
+bool lstm_step_fused_width(int nh);
+int lstm_step_fwd(float *z, int64_t z_stride, const float *wh, const float *hm, const float *cm, int64_t s_stride, int nenv,
+                  int nh, float *c, float *h, float *state_out, const uint8_t *mask_next, int64_t mask_stride, float *cm_next,
+                  float *hm_next, hipStream_t s);
+int lstm_step_bwd(float *gates, const float *dz_next, int64_t z_stride, const float *wh, const float *c, const float *cm,
+                  const float *dh_head, int64_t s_stride, float *dcm_carry, const uint8_t *mask_next, int64_t mask_stride,
+                  int nenv, int nh, hipStream_t s);
 // layer-normalised cell (a2c/utils.py:110-147); see lstm.hip for the buffer meanings
 struct LnLstmParams {
     const float *gx, *bx, *gh, *bh, *b, *gc, *bc;

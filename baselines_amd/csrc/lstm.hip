@@ -88,6 +88,190 @@ __global__ void lstm_gate_bwd_kernel(float *__restrict__ gates, int64_t z_stride
 }
 
 // ---------------------------------------------------------------------------------------
+// One launch per step and direction for the plain cell: the step's product and its element-wise half together.
+//
+// A workgroup (4 waves) owns a tile of 16 envs x 16 hidden units.  The product's k range is split over the four
+// waves, each lane quarter owning a run of consecutive k (the order of k inside an MFMA step is free as long as both
+// operands agree, and runs of consecutive k load as float4); the four partial tiles meet in LDS and are added in
+// wave order.  Thread (env, unit) of the tile then does the cell arithmetic for its element.
+//   forward : z[env, g nh + unit] += sum_k hm[env, k] wh[k, g nh + unit] for the four gates g, then the gates
+//   backward: dhm[env, unit] = sum_k dz_{t+1}[env, k] wh[unit, k] (k over the 4 nh gate columns), then the gate
+//             gradients of step t, which overwrite the step's gate rows
+// Operands go from L2 straight into registers (a step's whole operand set is 1.1 MB): all loads of a wave are in
+// flight before its first product.  nh must be a multiple of 64.
+// ---------------------------------------------------------------------------------------
+typedef float lf32x4 __attribute__((ext_vector_type(4)));
+#define LSTM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int NH>
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(float *__restrict__ z, int64_t z_stride, const float *__restrict__ wh,
+                                                            const float *__restrict__ hm, const float *__restrict__ cm,
+                                                            int64_t s_stride, int nenv, float *__restrict__ c,
+                                                            float *__restrict__ h, float *__restrict__ state_out,
+                                                            const uint8_t *__restrict__ mask_next, int64_t mask_stride,
+                                                            float *__restrict__ cm_next, float *__restrict__ hm_next) {
+    constexpr int KL = NH / 16;           // consecutive k per lane quarter (k range of a wave: NH / 4)
+    __shared__ float part[4][4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int u0 = blockIdx.x * 16, e0 = blockIdx.y * 16;
+    const int env_a = e0 + li < nenv ? e0 + li : nenv - 1;          // operand row of this lane (clamped; dropped on output)
+    const int kb = wave * (NH / 4) + lk * KL;
+    lf32x4 a4[KL / 4];
+    float b[KL][4];
+#pragma unroll
+    for (int q = 0; q < KL / 4; q++) a4[q] = *(const lf32x4 *)(hm + (int64_t)env_a * s_stride + kb + 4 * q);
+#pragma unroll
+    for (int s = 0; s < KL; s++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) b[s][g] = wh[(int64_t)(kb + s) * (4 * NH) + g * NH + u0 + li];
+    __builtin_amdgcn_sched_barrier(0);        // every load of the wave is in flight before its first product
+    lf32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) acc[g] = lf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KL; s++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[g] = LSTM_MFMA16(a4[s >> 2][s & 3], b[s][g], acc[g]);
+    // result register r of lane (li, lk): env 4 lk + r, unit li
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[wave][g][4 * lk + r][li] = acc[g][r];
+    __syncthreads();
+    const int el = tid >> 4, ul = tid & 15, e = e0 + el, j = u0 + ul;
+    if (e >= nenv) return;
+    float *zr = z + (int64_t)e * z_stride;
+    float zv[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+        zv[g] = zr[g * NH + j] + ((part[0][g][el][ul] + part[1][g][el][ul]) + (part[2][g][el][ul] + part[3][g][el][ul]));
+    const float i = sigmoidf(zv[0]), f = sigmoidf(zv[1]), o = sigmoidf(zv[2]), u = tanhf(zv[3]);
+    const int64_t sr = (int64_t)e * s_stride + j;
+    const float cn = f * cm[sr] + i * u;
+    const float hn = o * tanhf(cn);
+    zr[j] = i; zr[NH + j] = f; zr[2 * NH + j] = o; zr[3 * NH + j] = u;
+    c[sr] = cn;
+    h[sr] = hn;
+    if (state_out) {
+        state_out[(int64_t)e * 2 * NH + j] = cn;
+        state_out[(int64_t)e * 2 * NH + NH + j] = hn;
+    }
+    if (mask_next) {
+        const float keep = mask_next[(int64_t)e * mask_stride] ? 0.f : 1.f;
+        cm_next[sr] = cn * keep;
+        hm_next[sr] = hn * keep;
+    }
+}
+
+// dz_next: the gate-gradient rows of step t + 1 (null at the last step: no carry); gates: step t's rows, in: activated
+// gates, out: gate gradients; dcm_carry as in lstm_gate_bwd_kernel.
+template <int NH>
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(float *__restrict__ gates, const float *__restrict__ dz_next,
+                                                            int64_t z_stride, const float *__restrict__ wh,
+                                                            const float *__restrict__ c, const float *__restrict__ cm,
+                                                            const float *__restrict__ dh_head, int64_t s_stride,
+                                                            float *__restrict__ dcm_carry, const uint8_t *__restrict__ mask_next,
+                                                            int64_t mask_stride, int nenv) {
+    constexpr int KL = NH / 4;            // consecutive k per lane quarter (k = gate column, 4 NH of them; NH per wave)
+    __shared__ float part[4][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int u0 = blockIdx.x * 16, e0 = blockIdx.y * 16;
+    if (dz_next) {
+        const int env_a = e0 + li < nenv ? e0 + li : nenv - 1;
+        const int kb = wave * NH + lk * KL;
+        const float *ap = dz_next + (int64_t)env_a * z_stride + kb, *bp = wh + (int64_t)(u0 + li) * (4 * NH) + kb;
+        lf32x4 acc = lf32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int CH = KL / 4 < 8 ? KL / 4 : 8;       // float4 pairs in flight per round
+#pragma unroll
+        for (int q0 = 0; q0 < KL / 4; q0 += CH) {
+            lf32x4 a4[CH], b4[CH];
+#pragma unroll
+            for (int q = 0; q < CH; q++) {
+                a4[q] = *(const lf32x4 *)(ap + 4 * (q0 + q));
+                b4[q] = *(const lf32x4 *)(bp + 4 * (q0 + q));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < CH; q++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc = LSTM_MFMA16(a4[q][r], b4[q][r], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[wave][4 * lk + r][li] = acc[r];
+    }
+    __syncthreads();
+    const int el = tid >> 4, ul = tid & 15, e = e0 + el, j = u0 + ul;
+    if (e >= nenv) return;
+    float keep = 0.f, dhm = 0.f;
+    if (dz_next) {
+        keep = mask_next[(int64_t)e * mask_stride] ? 0.f : 1.f;
+        dhm = (part[0][el][ul] + part[1][el][ul]) + (part[2][el][ul] + part[3][el][ul]);
+    }
+    const int64_t sr = (int64_t)e * s_stride + j, cr = (int64_t)e * NH + j;
+    float *zr = gates + (int64_t)e * z_stride;
+    const float i = zr[j], f = zr[NH + j], o = zr[2 * NH + j], u = zr[3 * NH + j];
+    const float dh = dh_head[sr] + dhm * keep;
+    const float tc = tanhf(c[sr]);
+    const float dc = (dz_next ? dcm_carry[cr] * keep : 0.f) + dh * o * (1.f - tc * tc);
+    zr[j] = dc * u * i * (1.f - i);
+    zr[NH + j] = dc * cm[sr] * f * (1.f - f);
+    zr[2 * NH + j] = dh * tc * o * (1.f - o);
+    zr[3 * NH + j] = dc * i * (1.f - u * u);
+    dcm_carry[cr] = dc * f;
+}
+
+template <int NH>
+static int launch_step_fwd(float *z, int64_t z_stride, const float *wh, const float *hm, const float *cm, int64_t s_stride,
+                           int nenv, float *c, float *h, float *state_out, const uint8_t *mask_next, int64_t mask_stride,
+                           float *cm_next, float *hm_next, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_step_fwd_kernel<NH>, dim3(NH / 16, (unsigned)ceil_div(nenv, 16)), dim3(256), 0, s, z, z_stride, wh, hm,
+                       cm, s_stride, nenv, c, h, state_out, mask_next, mask_stride, cm_next, hm_next);
+    return check_launch("lstm_step_fwd_kernel");
+}
+template <int NH>
+static int launch_step_bwd(float *gates, const float *dz_next, int64_t z_stride, const float *wh, const float *c,
+                           const float *cm, const float *dh_head, int64_t s_stride, float *dcm_carry,
+                           const uint8_t *mask_next, int64_t mask_stride, int nenv, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_step_bwd_kernel<NH>, dim3(NH / 16, (unsigned)ceil_div(nenv, 16)), dim3(256), 0, s, gates, dz_next,
+                       z_stride, wh, c, cm, dh_head, s_stride, dcm_carry, mask_next, mask_stride, nenv);
+    return check_launch("lstm_step_bwd_kernel");
+}
+
+// widths with a compiled instance (the loops over k are unrolled per width)
+#define LSTM_FOR_WIDTH(nh, CALL)                 \
+    switch (nh) {                                \
+        case 64: return CALL(64);                \
+        case 128: return CALL(128);              \
+        case 256: return CALL(256);              \
+        case 512: return CALL(512);              \
+        default: break;                          \
+    }
+
+bool lstm_step_fused_width(int nh) { return nh == 64 || nh == 128 || nh == 256 || nh == 512; }
+
+int lstm_step_fwd(float *z, int64_t z_stride, const float *wh, const float *hm, const float *cm, int64_t s_stride, int nenv,
+                  int nh, float *c, float *h, float *state_out, const uint8_t *mask_next, int64_t mask_stride, float *cm_next,
+                  float *hm_next, hipStream_t s) {
+    if (nenv <= 0) return 0;
+#define CALL(N) launch_step_fwd<N>(z, z_stride, wh, hm, cm, s_stride, nenv, c, h, state_out, mask_next, mask_stride, cm_next, hm_next, s)
+    LSTM_FOR_WIDTH(nh, CALL)
+#undef CALL
+    set_error("lstm_step_fwd: no instance for nlstm=%d", nh);
+    return PPO2HIP_EUNSUPPORTED;
+}
+
+int lstm_step_bwd(float *gates, const float *dz_next, int64_t z_stride, const float *wh, const float *c, const float *cm,
+                  const float *dh_head, int64_t s_stride, float *dcm_carry, const uint8_t *mask_next, int64_t mask_stride,
+                  int nenv, int nh, hipStream_t s) {
+    if (nenv <= 0) return 0;
+#define CALL(N) launch_step_bwd<N>(gates, dz_next, z_stride, wh, c, cm, dh_head, s_stride, dcm_carry, mask_next, mask_stride, nenv, s)
+    LSTM_FOR_WIDTH(nh, CALL)
+#undef CALL
+    set_error("lstm_step_bwd: no instance for nlstm=%d", nh);
+    return PPO2HIP_EUNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------
 // Layer-normalised cell (baselines/a2c/utils.py:110-147):
 //   z = LN(x wx; gx, bx) + LN(hm wh; gh, bh) + b,   c = f cm + i u,   h = o tanh(LN(c; gc, bc)),
 //   LN(x; g, b) = (x - mean) / sqrt(var + 1e-5) * g + b over the row, var = mean((x - mean)^2).

@@ -427,11 +427,21 @@ static int lstm_forward_all(const ppo2hip_policy_desc &d, const Layout &L, const
     const float *wh = p + L.off("lstm1/wh");
     // step 0 masks the gathered initial state; every later step's masked states come out of the step before
     if ((rc = lstm_mask(w.S0, w.S0 + nh, 2 * nh, masks, T, nenv, nh, w.CM, w.HM, (int64_t)T * nh, s))) return rc;
+    // one launch per step (product and gates together) for the widths that have an instance; PPO2HIP_LSTM_STEPS=split
+    // keeps the product on the GEMM and the gates in a launch of their own
+    const char *steps_env = getenv("PPO2HIP_LSTM_STEPS");
+    const bool fused_steps = lstm_step_fused_width(nh) && (uintptr_t)wh % 16 == 0 && !(steps_env && std::strcmp(steps_env, "split") == 0);
     for (int t = 0; t < T; t++) {
         const int64_t o1 = (int64_t)t * nh, o4 = (int64_t)t * 4 * nh;
+        const bool last = t == T - 1;
+        if (fused_steps) {
+            if ((rc = lstm_step_fwd(w.Z + o4, (int64_t)T * 4 * nh, wh, w.HM + o1, w.CM + o1, (int64_t)T * nh, nenv, nh, w.C + o1,
+                                    w.Hs + o1, last ? state_out : nullptr, last ? nullptr : masks + t + 1, T,
+                                    last ? nullptr : w.CM + o1 + nh, last ? nullptr : w.HM + o1 + nh, s))) return rc;
+            continue;
+        }
         // partial products of hm_t wh (rows of step t are T rows apart), summed into z_t by the gate kernel
         if ((rc = fc_forward_parts(w.HM + o1, T * nh, wh, nenv, 4 * nh, nh, kLstmFwdParts, w.ZP, s))) return rc;
-        const bool last = t == T - 1;
         if ((rc = lstm_gates(w.Z + o4, (int64_t)T * 4 * nh, w.ZP, kLstmFwdParts, w.CM + o1, (int64_t)T * nh, nenv, nh, w.C + o1,
                              w.Hs + o1, last ? state_out : nullptr, last ? nullptr : masks + t + 1, T,
                              last ? nullptr : w.CM + o1 + nh, last ? nullptr : w.HM + o1 + nh, s))) return rc;
@@ -532,7 +542,16 @@ static int cnn_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
             if ((rc = ln_colsum(w.DL, nullptr, B, nh, grads + L.off("lstm1/bc"), s))) return rc;
             if ((rc = fc_dgrad(w.DZX, 4 * nh, p + L.off("lstm1/wx"), 512, 4 * nh, w.F, 512, ACT_RELU, w.dF, 512, (int)B, false, s))) return rc;
         } else {
-        for (int t = T - 1; t >= 0; t--) {
+        const char *steps_env = getenv("PPO2HIP_LSTM_STEPS");
+        const bool fused_steps = lstm_step_fused_width(nh) && (uintptr_t)wh % 16 == 0 && !(steps_env && std::strcmp(steps_env, "split") == 0);
+        for (int t = T - 1; fused_steps && t >= 0; t--) {
+            // dhm of step t + 1's gate gradients and step t's gate gradients in one launch
+            const bool last = t == T - 1;
+            if ((rc = lstm_step_bwd(w.Z + (int64_t)t * 4 * nh, last ? nullptr : w.Z + (int64_t)(t + 1) * 4 * nh, (int64_t)T * 4 * nh, wh,
+                                    w.C + (int64_t)t * nh, w.CM + (int64_t)t * nh, w.DH + (int64_t)t * nh, (int64_t)T * nh, w.dcm,
+                                    last ? nullptr : w.MASK + (t + 1), T, nenv, nh, s))) return rc;
+        }
+        for (int t = T - 1; !fused_steps && t >= 0; t--) {
             const uint8_t *mnext = t == T - 1 ? nullptr : w.MASK + (t + 1);
             if ((rc = lstm_gates_bwd(w.Z + (int64_t)t * 4 * nh, (int64_t)T * 4 * nh, w.C + (int64_t)t * nh, w.CM + (int64_t)t * nh,
                                      w.DH + (int64_t)t * nh, (int64_t)T * nh, w.dhm, kLstmBwdParts, w.dcm, mnext, T, nenv, nh, s))) return rc;
