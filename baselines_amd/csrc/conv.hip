@@ -44,6 +44,12 @@ __device__ inline void tap_advance(const ConvGeom &g, TapOff &t, int d) {
     const int kc = g.KW * g.Cin;
     t.rest += d;
     t.off += d;
+    if (d <= kc) {          // at most one kernel row further on: no per-lane loop (the test is uniform)
+        const bool wrap = t.rest >= kc;
+        t.rest -= wrap ? kc : 0;
+        t.off += wrap ? g.IW * g.Cin - kc : 0;
+        return;
+    }
     while (t.rest >= kc) {
         t.rest -= kc;
         t.off += g.IW * g.Cin - kc;
@@ -100,9 +106,22 @@ struct Im2colT {   // A(i = k, kk = m), row `ones_row` = 1
     __device__ Col col(int64_t m) const { return patch_row(c.g, m); }
     __device__ void advance_col(Col &p, int d) const {      // d output pixels further on
         const ConvGeom &g = c.g;
-        p.ow += d;
-        while (p.ow >= g.OW) { p.ow -= g.OW; p.oh++; }
-        while (p.oh >= g.OH) { p.oh -= g.OH; p.b++; }
+        // d = dq OW + dr pixels on: dq rows and dr columns, then at most one carry each way (uniform tests, no per-lane loops)
+        const int dq = d / g.OW, dr = d - dq * g.OW;
+        if (dq + 1 <= g.OH) {
+            p.ow += dr;
+            p.oh += dq;
+            const bool wc = p.ow >= g.OW;
+            p.ow -= wc ? g.OW : 0;
+            p.oh += wc ? 1 : 0;
+            const bool wr = p.oh >= g.OH;
+            p.oh -= wr ? g.OH : 0;
+            p.b += wr ? 1 : 0;
+        } else {
+            p.ow += d;
+            while (p.ow >= g.OW) { p.ow -= g.OW; p.oh++; }
+            while (p.oh >= g.OH) { p.oh -= g.OH; p.b++; }
+        }
         p.base = (((int64_t)p.b * g.IH + p.oh * g.S) * g.IW + p.ow * g.S) * g.Cin;
     }
     __device__ float at(const Row &r, const Col &p) const { return r < 0 ? 1.f : c.at_off(p.base, r); }
@@ -131,6 +150,15 @@ __device__ inline TapCol tap_col(int KW, int Cout, int64_t k) {
 // d taps further on in (kh, kw, co) order
 __device__ inline void tap_col_advance(int KW, int Cout, TapCol &t, int d) {
     t.co += d;
+    if (d <= Cout) {        // at most one tap further on: no per-lane loops (the test is uniform)
+        const bool wc = t.co >= Cout;
+        t.co -= wc ? Cout : 0;
+        t.kw += wc ? 1 : 0;
+        const bool wk = t.kw >= KW;
+        t.kw -= wk ? KW : 0;
+        t.kh += wk ? 1 : 0;
+        return;
+    }
     while (t.co >= Cout) { t.co -= Cout; t.kw++; }
     while (t.kw >= KW) { t.kw -= KW; t.kh++; }
 }
