@@ -5,6 +5,8 @@
 //   wgrad   : dW[k, co]         = sum_m col[m, k] dY[m, co]   (+ a ones row -> bias gradient), slabs over m
 //   dgrad   : dX[(b,ih,iw), ci] = relu'(X) * sum_{kh,kw,co} dY[b, (ih-kh)/s, (iw-kw)/s, co] W[kh,kw,ci,co]
 // uint8 observations are scaled by 1/255 inside the loader (tf.cast(...)/255., policies.py:10).
+#include <cstdlib>
+
 #include "gemm_core.hpp"
 #include "kernels.hpp"
 
@@ -220,6 +222,99 @@ struct DgradW {   // B(k = (kh,kw,co), n = ci) = W[kh, kw, ci, co]
     __device__ float at(const Row &t, const Col &c) const { return w[(t.kh * g.KW + t.kw) * g.Cin * g.Cout + t.co + c]; }
 };
 
+// Stride-1 input gradient without the border's zeros.  A border pixel of the input meets only some of the KH x KW taps
+// (for the 3x3 layer on 9x9 inputs, 441 of the 729 pixel-tap pairs exist), and in image order every tile of rows holds
+// pixels of all kinds, so the plain product multiplies the missing pairs as zeros.  Here rows are ordered
+//   m = (bt * npos + p) * 128 + bl,   image b = 128 bt + bl, pixel p = (ih, iw), npos = IH IW,
+// so a 128-row tile is one pixel of 128 images: its taps kh in [kh0, kh1], kw in [kw0, kw1] are the same for every row,
+// the k loop runs over exactly those (k' = ((kh - kh0) nkw + (kw - kw0)) Cout + co), no load needs a bounds test, and
+// consecutive tiles walk the pixels of the same 128 images (their dY stays in L2).  Needs B a multiple of 128.
+struct DgradColPM {   // A(m, k')
+    static constexpr bool kInnerFast = true;
+    static constexpr bool kTileK = true;
+    typedef PixelRow Row;
+    typedef TapCol Col;       // (kh - kh0, kw - kw0, co)
+    const float *dy;
+    ConvGeom g;
+    int kh0, kw0, nkw;
+    __device__ void begin_tile(int64_t m0, int64_t &kbeg, int64_t &kend) {
+        const int p = (int)((m0 / 128) % (g.IH * g.IW));
+        const int ih = p / g.IW, iw = p - ih * g.IW;
+        kh0 = ih - (g.OH - 1) > 0 ? ih - (g.OH - 1) : 0;
+        kw0 = iw - (g.OW - 1) > 0 ? iw - (g.OW - 1) : 0;
+        const int kh1 = ih < g.KH - 1 ? ih : g.KH - 1, kw1 = iw < g.KW - 1 ? iw : g.KW - 1;
+        nkw = kw1 - kw0 + 1;
+        kbeg = 0;
+        kend = (int64_t)(kh1 - kh0 + 1) * nkw * g.Cout;
+    }
+    __device__ Row row(int64_t m) const {
+        const int npos = g.IH * g.IW;
+        const int64_t bt = m / ((int64_t)npos * 128);
+        const int rem = (int)(m - bt * npos * 128);
+        const int p = rem >> 7, bl = rem & 127;
+        Row r;
+        r.ih = p / g.IW;
+        r.iw = p - r.ih * g.IW;
+        r.bbase = (bt * 128 + bl) * g.OH * g.OW * g.Cout;
+        return r;
+    }
+    __device__ Col col(int64_t k) const { return tap_col(nkw, g.Cout, k); }
+    __device__ void advance_col(Col &t, int d) const { tap_col_advance(nkw, g.Cout, t, d); }
+    __device__ int64_t offset(const Row &p, const Col &t) const {
+        return p.bbase + (int64_t)((p.ih - kh0 - t.kh) * g.OW + (p.iw - kw0 - t.kw)) * g.Cout + t.co;
+    }
+    __device__ float at(const Row &p, const Col &t) const { return dy[offset(p, t)]; }
+    static constexpr int kVec = 4;
+    int vec_width() const { return aligned16(dy) && g.Cout % 4 == 0 ? 4 : 1; }
+    __device__ void at_vec(const Row &p, const Col &t, float (&o)[4]) const {
+        const float4 v = *(const float4 *)(dy + offset(p, t));
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+};
+struct DgradWPM {   // B(k', n = ci) = W[kh0 + kh', kw0 + kw', ci, co]
+    static constexpr bool kInnerFast = false;
+    static constexpr bool kTileK = true;
+    static constexpr int kVec = 4;
+    int vec_width() const { return aligned16(w) && g.Cout % 4 == 0 ? 4 : 1; }
+    typedef TapCol Row;
+    typedef int Col;
+    const float *w;
+    ConvGeom g;
+    int kh0, kw0, nkw;
+    __device__ void begin_tile(int64_t m0) {
+        const int p = (int)((m0 / 128) % (g.IH * g.IW));
+        const int ih = p / g.IW, iw = p - ih * g.IW;
+        kh0 = ih - (g.OH - 1) > 0 ? ih - (g.OH - 1) : 0;
+        kw0 = iw - (g.OW - 1) > 0 ? iw - (g.OW - 1) : 0;
+        const int kw1 = iw < g.KW - 1 ? iw : g.KW - 1;
+        nkw = kw1 - kw0 + 1;
+    }
+    __device__ Row row(int64_t k) const { return tap_col(nkw, g.Cout, k); }
+    __device__ void advance_row(Row &t, int d) const { tap_col_advance(nkw, g.Cout, t, d); }
+    __device__ Col col(int64_t n) const { return (int)n * g.Cout; }
+    __device__ int offset(const Row &t, const Col &c) const {
+        return ((kh0 + t.kh) * g.KW + kw0 + t.kw) * g.Cin * g.Cout + t.co + c;
+    }
+    __device__ float at(const Row &t, const Col &c) const { return w[offset(t, c)]; }
+    __device__ void at_vec(const Row &t, const Col &c, float (&o)[4]) const {
+        const float4 v = *(const float4 *)(w + offset(t, c));
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+};
+struct EpiActGradPM {   // row m of the pixel-major order -> pixel (b, p) of dX, times relu'(X)
+    typedef int64_t Row;
+    float *dX;
+    const float *Xact;
+    ConvGeom g;
+    __device__ Row row(int64_t m, int) const {
+        const int npos = g.IH * g.IW;
+        const int64_t bt = m / ((int64_t)npos * 128);
+        const int rem = (int)(m - bt * npos * 128);
+        return ((bt * 128 + (rem & 127)) * npos + (rem >> 7)) * g.Cin;
+    }
+    __device__ void operator()(const Row &r, int n, float v) const { dX[r + n] = Xact[r + n] > 0.f ? v : 0.f; }
+};
+
 static ConvGeom geom(const ConvShape &c) {
     return ConvGeom{c.IH, c.IW, c.Cin, c.KH, c.KW, c.stride, c.OH, c.OW, c.Cout};
 }
@@ -349,6 +444,11 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
     }
     const int64_t M = (int64_t)c.B * c.IH * c.IW;
     const int K = c.KH * c.KW * c.Cout;
+    if (c.stride == 1 && c.B % 128 == 0 && c.Cin <= GEMM_BN && M >= 1024 && c.KH <= c.IH && c.KW <= c.IW && !getenv("PPO2HIP_DGRAD_PLAIN")) {
+        // tiles of one pixel x 128 images: only the taps that pixel meets (launch_gemm takes 128-row tiles at these sizes)
+        return launch_gemm(DgradColPM{dY, geom(c), 0, 0, 0}, DgradWPM{W, geom(c), 0, 0, 0}, EpiActGradPM{dX, Xact, geom(c)}, M, c.Cin, K, 1,
+                           s, "conv_dgrad");
+    }
     EpiActGrad ep{dX, c.Cin, Xact, c.Cin, ACT_RELU, 0};
     return launch_gemm(DgradCol{dY, geom(c)}, DgradW{W, geom(c)}, ep, M, c.Cin, K, 1, s, "conv_dgrad");
 }

@@ -12,6 +12,7 @@
 // the current one feeds the matrix cores.
 #pragma once
 #include <cstdint>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -40,6 +41,12 @@ constexpr int GEMM_THREADS = 256;
 //   its MFMA work for the narrow (few output columns) and byte-input products.
 // Epilogue concept: Row row(int64_t m, int z) const — what the output address owes to the row (and the slab);
 //                   void operator()(const Row &, int n, float acc) const
+
+// a loader with `static constexpr bool kTileK = true` has begin_tile(m0, kbeg, kend) (A) / begin_tile(m0) (B)
+template <class L, class = void>
+struct tile_k : std::false_type {};
+template <class L>
+struct tile_k<L, std::enable_if_t<L::kTileK>> : std::true_type {};
 
 // LDS row pitch: rows lh = 0 / 1 of an operand read must land on different bank halves (pitch = 32 mod 64)
 // when rows are written as vectors; the scalar path keeps the odd pitch that spreads its k-fast writes.
@@ -74,8 +81,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int z = blockIdx.z;
-    const int64_t kbeg = (int64_t)z * klen;
-    const int64_t kend = kbeg + klen < K ? kbeg + klen : K;
+    int64_t kbeg = (int64_t)z * klen;
+    int64_t kend = kbeg + klen < K ? kbeg + klen : K;
+    // loaders whose k range depends on the tile (a product that skips what is zero for all of a tile's rows) set
+    // themselves up for this tile and say which k it runs over
+    if constexpr (tile_k<AL>::value) {
+        a.begin_tile(m0, kbeg, kend);
+        b.begin_tile(m0);
+    }
 
     f32x16 acc[NB];
 #pragma unroll
