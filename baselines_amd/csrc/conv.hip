@@ -222,78 +222,86 @@ struct DgradW {   // B(k = (kh,kw,co), n = ci) = W[kh, kw, ci, co]
     __device__ float at(const Row &t, const Col &c) const { return w[(t.kh * g.KW + t.kw) * g.Cin * g.Cout + t.co + c]; }
 };
 
-// Stride-1 input gradient without the border's zeros.  A border pixel of the input meets only some of the KH x KW taps
-// (for the 3x3 layer on 9x9 inputs, 441 of the 729 pixel-tap pairs exist), and in image order every tile of rows holds
-// pixels of all kinds, so the plain product multiplies the missing pairs as zeros.  Here rows are ordered
-//   m = (bt * npos + p) * 128 + bl,   image b = 128 bt + bl, pixel p = (ih, iw), npos = IH IW,
-// so a 128-row tile is one pixel of 128 images: its taps kh in [kh0, kh1], kw in [kw0, kw1] are the same for every row,
-// the k loop runs over exactly those (k' = ((kh - kh0) nkw + (kw - kw0)) Cout + co), no load needs a bounds test, and
+// Input gradient without the border's zeros.  A border pixel of the input meets only some of the taps (for the 3x3
+// stride-1 layer on 9x9 inputs, 441 of the 729 pixel-tap pairs exist; for a parity class of the 4x4 stride-2 layer 81 %),
+// and in image order every tile of rows holds pixels of all kinds, so the plain product multiplies the missing pairs as
+// zeros.  Here rows are ordered
+//   m = (bt * npos + p) * 128 + bl,   image b = 128 bt + bl, pixel p = (ih', iw') of the class, npos = IHp IWp,
+// so a 128-row tile is one pixel of 128 images: its taps kh' in [kh0, kh1], kw' in [kw0, kw1] are the same for every row,
+// the k loop runs over exactly those (k' = ((kh' - kh0) nkw + (kw' - kw0)) Cout + co), no load needs a bounds test, and
 // consecutive tiles walk the pixels of the same 128 images (their dY stays in L2).  Needs B a multiple of 128.
+// A stride-1 layer is the single class ph = pw = 0, S = 1, IHp = IH, KHp = KH; for a strided layer (see conv_dgrad) input
+// pixel (S ih' + ph, S iw' + pw) meets taps (ph + S kh', pw + S kw') at output pixel (ih' - kh', iw' - kw').
+struct PixelMajor {
+    ConvGeom g;
+    int ph, pw, IHp, IWp, KHp, KWp;
+    int kh0, kw0, nkw;       // set per tile
+    __device__ int taps_of_tile(int64_t m0) {
+        const int p = (int)((m0 / 128) % (IHp * IWp));
+        const int ih = p / IWp, iw = p - ih * IWp;
+        kh0 = ih - (g.OH - 1) > 0 ? ih - (g.OH - 1) : 0;
+        kw0 = iw - (g.OW - 1) > 0 ? iw - (g.OW - 1) : 0;
+        const int kh1 = ih < KHp - 1 ? ih : KHp - 1, kw1 = iw < KWp - 1 ? iw : KWp - 1;
+        nkw = kw1 - kw0 + 1;
+        return (kh1 - kh0 + 1) * nkw;
+    }
+    // row m -> (image, pixel of the class)
+    __device__ void decode(int64_t m, int64_t &b, int &ih, int &iw) const {
+        const int npos = IHp * IWp;
+        const int64_t bt = m / ((int64_t)npos * 128);
+        const int rem = (int)(m - bt * npos * 128);
+        const int p = rem >> 7;
+        b = bt * 128 + (rem & 127);
+        ih = p / IWp;
+        iw = p - ih * IWp;
+    }
+};
 struct DgradColPM {   // A(m, k')
     static constexpr bool kInnerFast = true;
     static constexpr bool kTileK = true;
     typedef PixelRow Row;
-    typedef TapCol Col;       // (kh - kh0, kw - kw0, co)
+    typedef TapCol Col;       // (kh' - kh0, kw' - kw0, co)
     const float *dy;
-    ConvGeom g;
-    int kh0, kw0, nkw;
+    PixelMajor q;
     __device__ void begin_tile(int64_t m0, int64_t &kbeg, int64_t &kend) {
-        const int p = (int)((m0 / 128) % (g.IH * g.IW));
-        const int ih = p / g.IW, iw = p - ih * g.IW;
-        kh0 = ih - (g.OH - 1) > 0 ? ih - (g.OH - 1) : 0;
-        kw0 = iw - (g.OW - 1) > 0 ? iw - (g.OW - 1) : 0;
-        const int kh1 = ih < g.KH - 1 ? ih : g.KH - 1, kw1 = iw < g.KW - 1 ? iw : g.KW - 1;
-        nkw = kw1 - kw0 + 1;
         kbeg = 0;
-        kend = (int64_t)(kh1 - kh0 + 1) * nkw * g.Cout;
+        kend = (int64_t)q.taps_of_tile(m0) * q.g.Cout;
     }
     __device__ Row row(int64_t m) const {
-        const int npos = g.IH * g.IW;
-        const int64_t bt = m / ((int64_t)npos * 128);
-        const int rem = (int)(m - bt * npos * 128);
-        const int p = rem >> 7, bl = rem & 127;
         Row r;
-        r.ih = p / g.IW;
-        r.iw = p - r.ih * g.IW;
-        r.bbase = (bt * 128 + bl) * g.OH * g.OW * g.Cout;
+        int64_t b;
+        q.decode(m, b, r.ih, r.iw);
+        r.bbase = b * q.g.OH * q.g.OW * q.g.Cout;
         return r;
     }
-    __device__ Col col(int64_t k) const { return tap_col(nkw, g.Cout, k); }
-    __device__ void advance_col(Col &t, int d) const { tap_col_advance(nkw, g.Cout, t, d); }
+    __device__ Col col(int64_t k) const { return tap_col(q.nkw, q.g.Cout, k); }
+    __device__ void advance_col(Col &t, int d) const { tap_col_advance(q.nkw, q.g.Cout, t, d); }
     __device__ int64_t offset(const Row &p, const Col &t) const {
-        return p.bbase + (int64_t)((p.ih - kh0 - t.kh) * g.OW + (p.iw - kw0 - t.kw)) * g.Cout + t.co;
+        return p.bbase + (int64_t)((p.ih - q.kh0 - t.kh) * q.g.OW + (p.iw - q.kw0 - t.kw)) * q.g.Cout + t.co;
     }
     __device__ float at(const Row &p, const Col &t) const { return dy[offset(p, t)]; }
     static constexpr int kVec = 4;
-    int vec_width() const { return aligned16(dy) && g.Cout % 4 == 0 ? 4 : 1; }
+    int vec_width() const { return aligned16(dy) && q.g.Cout % 4 == 0 ? 4 : 1; }
     __device__ void at_vec(const Row &p, const Col &t, float (&o)[4]) const {
         const float4 v = *(const float4 *)(dy + offset(p, t));
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     }
 };
-struct DgradWPM {   // B(k', n = ci) = W[kh0 + kh', kw0 + kw', ci, co]
+struct DgradWPM {   // B(k', n = ci) = W[ph + S (kh0 + kh'), pw + S (kw0 + kw'), ci, co]
     static constexpr bool kInnerFast = false;
     static constexpr bool kTileK = true;
     static constexpr int kVec = 4;
-    int vec_width() const { return aligned16(w) && g.Cout % 4 == 0 ? 4 : 1; }
+    int vec_width() const { return aligned16(w) && q.g.Cout % 4 == 0 ? 4 : 1; }
     typedef TapCol Row;
     typedef int Col;
     const float *w;
-    ConvGeom g;
-    int kh0, kw0, nkw;
-    __device__ void begin_tile(int64_t m0) {
-        const int p = (int)((m0 / 128) % (g.IH * g.IW));
-        const int ih = p / g.IW, iw = p - ih * g.IW;
-        kh0 = ih - (g.OH - 1) > 0 ? ih - (g.OH - 1) : 0;
-        kw0 = iw - (g.OW - 1) > 0 ? iw - (g.OW - 1) : 0;
-        const int kw1 = iw < g.KW - 1 ? iw : g.KW - 1;
-        nkw = kw1 - kw0 + 1;
-    }
-    __device__ Row row(int64_t k) const { return tap_col(nkw, g.Cout, k); }
-    __device__ void advance_row(Row &t, int d) const { tap_col_advance(nkw, g.Cout, t, d); }
-    __device__ Col col(int64_t n) const { return (int)n * g.Cout; }
+    PixelMajor q;
+    __device__ void begin_tile(int64_t m0) { q.taps_of_tile(m0); }
+    __device__ Row row(int64_t k) const { return tap_col(q.nkw, q.g.Cout, k); }
+    __device__ void advance_row(Row &t, int d) const { tap_col_advance(q.nkw, q.g.Cout, t, d); }
+    __device__ Col col(int64_t n) const { return (int)n * q.g.Cout; }
     __device__ int offset(const Row &t, const Col &c) const {
-        return ((kh0 + t.kh) * g.KW + kw0 + t.kw) * g.Cin * g.Cout + t.co + c;
+        return ((q.ph + q.g.S * (q.kh0 + t.kh)) * q.g.KW + q.pw + q.g.S * (q.kw0 + t.kw)) * q.g.Cin * q.g.Cout + t.co + c;
     }
     __device__ float at(const Row &t, const Col &c) const { return w[offset(t, c)]; }
     __device__ void at_vec(const Row &t, const Col &c, float (&o)[4]) const {
@@ -301,16 +309,16 @@ struct DgradWPM {   // B(k', n = ci) = W[kh0 + kh', kw0 + kw', ci, co]
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     }
 };
-struct EpiActGradPM {   // row m of the pixel-major order -> pixel (b, p) of dX, times relu'(X)
+struct EpiActGradPM {   // row m of the pixel-major order -> pixel (b, S ih' + ph, S iw' + pw) of dX, times relu'(X)
     typedef int64_t Row;
     float *dX;
     const float *Xact;
-    ConvGeom g;
+    PixelMajor q;
     __device__ Row row(int64_t m, int) const {
-        const int npos = g.IH * g.IW;
-        const int64_t bt = m / ((int64_t)npos * 128);
-        const int rem = (int)(m - bt * npos * 128);
-        return ((bt * 128 + (rem & 127)) * npos + (rem >> 7)) * g.Cin;
+        int64_t b;
+        int ih, iw;
+        q.decode(m, b, ih, iw);
+        return ((b * q.g.IH + q.g.S * ih + q.ph) * q.g.IW + q.g.S * iw + q.pw) * q.g.Cin;
     }
     __device__ void operator()(const Row &r, int n, float v) const { dX[r + n] = Xact[r + n] > 0.f ? v : 0.f; }
 };
@@ -427,6 +435,12 @@ struct EpiActGradP {   // row m' of a parity class -> pixel (b, S ih' + ph, S iw
     __device__ void operator()(const Row &r, int n, float v) const { dX[r + n] = Xact[r + n] > 0.f ? v : 0.f; }
 };
 
+// pixel-major tiles: whole groups of 128 images, and enough rows that launch_gemm takes its 128-row tiles;
+// PPO2HIP_DGRAD_PLAIN=1 keeps the image-major products
+static bool pixel_major_ok(const ConvShape &c, int64_t M) {
+    return c.B % 128 == 0 && M >= 1024 && !getenv("PPO2HIP_DGRAD_PLAIN");
+}
+
 int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, const ConvShape &c, hipStream_t s) {
     if (c.stride > 1 && c.KH % c.stride == 0 && c.KW % c.stride == 0) {
         const int S = c.stride, KHp = c.KH / S, KWp = c.KW / S;
@@ -436,6 +450,12 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
                 if (IHp <= 0 || IWp <= 0) continue;
                 const int64_t M = (int64_t)c.B * IHp * IWp;
                 const int K = KHp * KWp * c.Cout;
+                if (pixel_major_ok(c, M) && KHp <= IHp && KWp <= IWp) {
+                    const PixelMajor q{geom(c), ph, pw, IHp, IWp, KHp, KWp, 0, 0, 0};
+                    int rc = launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q}, M, c.Cin, K, 1, s, "conv_dgrad");
+                    if (rc) return rc;
+                    continue;
+                }
                 int rc = launch_gemm(DgradColP{dY, geom(c), ph, pw, IHp, IWp, KWp}, DgradWP{W, geom(c), ph, pw, KWp},
                                      EpiActGradP{dX, Xact, geom(c), ph, pw, IHp, IWp}, M, c.Cin, K, 1, s, "conv_dgrad");
                 if (rc) return rc;
@@ -444,10 +464,9 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
     }
     const int64_t M = (int64_t)c.B * c.IH * c.IW;
     const int K = c.KH * c.KW * c.Cout;
-    if (c.stride == 1 && c.B % 128 == 0 && c.Cin <= GEMM_BN && M >= 1024 && c.KH <= c.IH && c.KW <= c.IW && !getenv("PPO2HIP_DGRAD_PLAIN")) {
-        // tiles of one pixel x 128 images: only the taps that pixel meets (launch_gemm takes 128-row tiles at these sizes)
-        return launch_gemm(DgradColPM{dY, geom(c), 0, 0, 0}, DgradWPM{W, geom(c), 0, 0, 0}, EpiActGradPM{dX, Xact, geom(c)}, M, c.Cin, K, 1,
-                           s, "conv_dgrad");
+    if (c.stride == 1 && pixel_major_ok(c, M) && c.KH <= c.IH && c.KW <= c.IW) {
+        const PixelMajor q{geom(c), 0, 0, c.IH, c.IW, c.KH, c.KW, 0, 0, 0};
+        return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q}, M, c.Cin, K, 1, s, "conv_dgrad");
     }
     EpiActGrad ep{dX, c.Cin, Xact, c.Cin, ACT_RELU, 0};
     return launch_gemm(DgradCol{dY, geom(c)}, DgradW{W, geom(c)}, ep, M, c.Cin, K, 1, s, "conv_dgrad");
