@@ -232,9 +232,13 @@ struct DgradW {   // B(k = (kh,kw,co), n = ci) = W[kh, kw, ci, co]
 // consecutive tiles walk the pixels of the same 128 images (their dY stays in L2).  Needs B a multiple of 128.
 // A stride-1 layer is the single class ph = pw = 0, S = 1, IHp = IH, KHp = KH; for a strided layer (see conv_dgrad) input
 // pixel (S ih' + ph, S iw' + pw) meets taps (ph + S kh', pw + S kw') at output pixel (ih' - kh', iw' - kw').
+// The dY operand of a class does not depend on (ph, pw) at all, only the weights do: when the classes have one size
+// (IH, IW multiples of S) they run as ONE product with the classes side by side along n = (ph, pw, ci), `merged`, which
+// reads and stages every dY element once for S x S Cin output columns instead of once per class for Cin.
 struct PixelMajor {
     ConvGeom g;
     int ph, pw, IHp, IWp, KHp, KWp;
+    int merged;              // columns n = ((ph, pw), ci) for all S x S classes (ph, pw above are 0 then)
     int kh0, kw0, nkw;       // set per tile
     __device__ int taps_of_tile(int64_t m0) {
         const int p = (int)((m0 / 128) % (IHp * IWp));
@@ -299,9 +303,14 @@ struct DgradWPM {   // B(k', n = ci) = W[ph + S (kh0 + kh'), pw + S (kw0 + kw'),
     __device__ void begin_tile(int64_t m0) { q.taps_of_tile(m0); }
     __device__ Row row(int64_t k) const { return tap_col(q.nkw, q.g.Cout, k); }
     __device__ void advance_row(Row &t, int d) const { tap_col_advance(q.nkw, q.g.Cout, t, d); }
-    __device__ Col col(int64_t n) const { return (int)n * q.g.Cout; }
+    // what a column owes to the offset: its class's first tap and its input channel
+    __device__ Col col(int64_t n) const {
+        const int cls = q.merged ? (int)n / q.g.Cin : 0, ci = (int)n - cls * q.g.Cin;
+        const int ph = q.merged ? cls / q.g.S : q.ph, pw = q.merged ? cls - (cls / q.g.S) * q.g.S : q.pw;
+        return ((ph * q.g.KW + pw) * q.g.Cin + ci) * q.g.Cout;
+    }
     __device__ int offset(const Row &t, const Col &c) const {
-        return ((q.ph + q.g.S * (q.kh0 + t.kh)) * q.g.KW + q.pw + q.g.S * (q.kw0 + t.kw)) * q.g.Cin * q.g.Cout + t.co + c;
+        return (q.g.S * (q.kh0 + t.kh) * q.g.KW + q.g.S * (q.kw0 + t.kw)) * q.g.Cin * q.g.Cout + t.co + c;
     }
     __device__ float at(const Row &t, const Col &c) const { return w[offset(t, c)]; }
     __device__ void at_vec(const Row &t, const Col &c, float (&o)[4]) const {
@@ -320,7 +329,14 @@ struct EpiActGradPM {   // row m of the pixel-major order -> pixel (b, S ih' + p
         q.decode(m, b, ih, iw);
         return ((b * q.g.IH + q.g.S * ih + q.ph) * q.g.IW + q.g.S * iw + q.pw) * q.g.Cin;
     }
-    __device__ void operator()(const Row &r, int n, float v) const { dX[r + n] = Xact[r + n] > 0.f ? v : 0.f; }
+    __device__ void operator()(const Row &r, int n, float v) const {
+        int64_t o = r + n;
+        if (q.merged) {          // column n = ((ph, pw), ci): the pixel of its class
+            const int cls = n / q.g.Cin, ci = n - cls * q.g.Cin, ph = cls / q.g.S, pw = cls - ph * q.g.S;
+            o = r + (int64_t)(ph * q.g.IW + pw) * q.g.Cin + ci;
+        }
+        dX[o] = Xact[o] > 0.f ? v : 0.f;
+    }
 };
 
 static ConvGeom geom(const ConvShape &c) {
@@ -444,6 +460,14 @@ static bool pixel_major_ok(const ConvShape &c, int64_t M) {
 int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, const ConvShape &c, hipStream_t s) {
     if (c.stride > 1 && c.KH % c.stride == 0 && c.KW % c.stride == 0) {
         const int S = c.stride, KHp = c.KH / S, KWp = c.KW / S;
+        if (c.IH % S == 0 && c.IW % S == 0 && pixel_major_ok(c, (int64_t)c.B * (c.IH / S) * (c.IW / S)) && KHp <= c.IH / S &&
+            KWp <= c.IW / S && !getenv("PPO2HIP_DGRAD_PER_CLASS")) {
+            // all S x S classes in one product: n = ((ph, pw), ci)
+            const int IHp = c.IH / S, IWp = c.IW / S;
+            const PixelMajor q{geom(c), 0, 0, IHp, IWp, KHp, KWp, 1, 0, 0, 0};
+            return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q}, (int64_t)c.B * IHp * IWp, S * S * c.Cin,
+                               KHp * KWp * c.Cout, 1, s, "conv_dgrad");
+        }
         for (int ph = 0; ph < S; ph++)
             for (int pw = 0; pw < S; pw++) {
                 const int IHp = (c.IH - ph + S - 1) / S, IWp = (c.IW - pw + S - 1) / S;
@@ -451,7 +475,7 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
                 const int64_t M = (int64_t)c.B * IHp * IWp;
                 const int K = KHp * KWp * c.Cout;
                 if (pixel_major_ok(c, M) && KHp <= IHp && KWp <= IWp) {
-                    const PixelMajor q{geom(c), ph, pw, IHp, IWp, KHp, KWp, 0, 0, 0};
+                    const PixelMajor q{geom(c), ph, pw, IHp, IWp, KHp, KWp, 0, 0, 0, 0};
                     int rc = launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q}, M, c.Cin, K, 1, s, "conv_dgrad");
                     if (rc) return rc;
                     continue;
@@ -465,7 +489,7 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
     const int64_t M = (int64_t)c.B * c.IH * c.IW;
     const int K = c.KH * c.KW * c.Cout;
     if (c.stride == 1 && pixel_major_ok(c, M) && c.KH <= c.IH && c.KW <= c.IW) {
-        const PixelMajor q{geom(c), 0, 0, c.IH, c.IW, c.KH, c.KW, 0, 0, 0};
+        const PixelMajor q{geom(c), 0, 0, c.IH, c.IW, c.KH, c.KW, 0, 0, 0, 0};
         return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q}, M, c.Cin, K, 1, s, "conv_dgrad");
     }
     EpiActGrad ep{dX, c.Cin, Xact, c.Cin, ACT_RELU, 0};
