@@ -67,7 +67,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     constexpr int WN = 4 / WM;              // wave columns
     constexpr int BN = 32 * WN * NB;
     constexpr bool A_KG_FAST = AL::kInnerFast && AV > 1 && AV < GEMM_BK;   // several k groups per row and slab
-    constexpr int LDA = lds_pitch(BM, AV == 1 ? 0 : A_KG_FAST ? 2 : 1), LDB = lds_pitch(BN, BV == 1 ? 0 : BL::kInnerFast ? 1 : 2);
+    // m-contiguous A read sixteen at a time (uint8 taps): lanes run along k, so that a wave's sixteen-byte loads are
+    // consecutive pixels (contiguous in memory for a stride of four 4-channel pixels) and its four 16-byte LDS writes per
+    // lane land on sixteen different rows, which the 36-mod-64 pitch spreads over all banks
+    constexpr bool A_K_LANES = !AL::kInnerFast && AV == GEMM_BK;
+    constexpr int LDA = lds_pitch(BM, AV == 1 ? 0 : (A_KG_FAST || A_K_LANES) ? 2 : 1), LDB = lds_pitch(BN, BV == 1 ? 0 : BL::kInnerFast ? 1 : 2);
     // element-wise: elements per thread; vector: tasks (one wide load each) per thread
     constexpr int A_TASKS_ALL = BM * GEMM_BK / AV, B_TASKS_ALL = BN * GEMM_BK / BV;
     constexpr int A_PER = (A_TASKS_ALL + GEMM_THREADS - 1) / GEMM_THREADS;
@@ -137,11 +141,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
 #pragma unroll
             for (int e = 0; e < A_PER; e++) acol[e] = a.col(kbeg + ((tid + e * GEMM_THREADS) / BM) * AV);
         } else {
-            const int64_t m = m0 + (tid % A_MG) * AV;
+            const int64_t m = m0 + (A_K_LANES ? tid / GEMM_BK : tid % A_MG) * AV;
             a_ok[0] = m < M;                             // M is a multiple of AV: a group is all in or all out
             arow[0] = a.row(a_ok[0] ? m : 0);
 #pragma unroll
-            for (int e = 0; e < A_PER; e++) acol[e] = a.col(kbeg + (tid + e * GEMM_THREADS) / A_MG);
+            for (int e = 0; e < A_PER; e++) acol[e] = a.col(kbeg + (A_K_LANES ? tid % GEMM_BK : (tid + e * GEMM_THREADS) / A_MG));
         }
     } else if constexpr (AL::kInnerFast) {
 #pragma unroll
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
 #pragma unroll
             for (int e = 0; e < A_PER; e++) {
                 const int t = tid + e * GEMM_THREADS;
-                const int64_t k = k0 + t / A_MG;
+                const int64_t k = k0 + (A_K_LANES ? t % GEMM_BK : t / A_MG);
                 if (t < A_TASKS_ALL && a_ok[0] && k < kend) {
                     a.at_vec(arow[0], acol[e], areg[e]);
                 } else {
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
                 }
             } else if constexpr (AV > 1) {
                 if (lin < A_TASKS_ALL) {
-                    float *dst = &As[(lin / A_MG) * LDA + (lin % A_MG) * AV];
+                    float *dst = A_K_LANES ? &As[(lin % GEMM_BK) * LDA + (lin / GEMM_BK) * AV] : &As[(lin / A_MG) * LDA + (lin % A_MG) * AV];
 #pragma unroll
                     for (int q = 0; q < AV / 4; q++)
                         *(float4 *)(dst + 4 * q) = make_float4(areg[e][4 * q], areg[e][4 * q + 1], areg[e][4 * q + 2], areg[e][4 * q + 3]);
