@@ -319,23 +319,27 @@ struct DgradWPM {   // B(k', n = ci) = W[ph + S (kh0 + kh'), pw + S (kw0 + kw'),
     }
 };
 struct EpiActGradPM {   // row m of the pixel-major order -> pixel (b, S ih' + ph, S iw' + pw) of dX, times relu'(X)
+    static constexpr bool kColSum = true;
     typedef int64_t Row;
     float *dX;
     const float *Xact;
     PixelMajor q;
+    float *colsum;           // [row tiles][N] column sums of the stored values, or null
     __device__ Row row(int64_t m, int) const {
         int64_t b;
         int ih, iw;
         q.decode(m, b, ih, iw);
         return ((b * q.g.IH + q.g.S * ih + q.ph) * q.g.IW + q.g.S * iw + q.pw) * q.g.Cin;
     }
-    __device__ void operator()(const Row &r, int n, float v) const {
+    __device__ float operator()(const Row &r, int n, float v) const {
         int64_t o = r + n;
         if (q.merged) {          // column n = ((ph, pw), ci): the pixel of its class
             const int cls = n / q.g.Cin, ci = n - cls * q.g.Cin, ph = cls / q.g.S, pw = cls - ph * q.g.S;
             o = r + (int64_t)(ph * q.g.IW + pw) * q.g.Cin + ci;
         }
-        dX[o] = Xact[o] > 0.f ? v : 0.f;
+        v = Xact[o] > 0.f ? v : 0.f;
+        dX[o] = v;
+        return v;
     }
 };
 
@@ -359,7 +363,7 @@ int conv_wgrad_max_slabs(const ConvShape &c) {
 }
 
 int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape &c, float *slabs, int max_slabs,
-                     int *nslabs, hipStream_t s) {
+                     int *nslabs, hipStream_t s, bool bias_rows) {
     const int64_t M = (int64_t)c.B * c.OH * c.OW;
     const int K = c.KH * c.KW * c.Cin;
     int n = conv_wgrad_max_slabs(c);
@@ -372,7 +376,7 @@ int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape 
     int rc;
     if (x_u8) rc = launch_gemm(Im2colT<true>{Im2col<true>{X, geom(c)}, ones}, Bm, ep, rows, c.Cout, M, n, s, "conv_wgrad");
     else rc = launch_gemm(Im2colT<false>{Im2col<false>{X, geom(c)}, ones}, Bm, ep, rows, c.Cout, M, n, s, "conv_wgrad");
-    if (rc || !sep) return rc;
+    if (rc || !sep || !bias_rows) return rc;
     return slab_bias_rows(dY, c.Cout, M, K, c.Cout, slabs, n, s);
 }
 
@@ -457,7 +461,15 @@ static bool pixel_major_ok(const ConvShape &c, int64_t M) {
     return c.B % 128 == 0 && M >= 1024 && !getenv("PPO2HIP_DGRAD_PLAIN");
 }
 
-int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, const ConvShape &c, hipStream_t s) {
+// rows of Cin column sums conv_dgrad may hand back (row tiles x parity classes of the largest route)
+int64_t conv_dgrad_colsum_rows(const ConvShape &c) {
+    const int S = c.stride > 0 ? c.stride : 1;
+    return ceil_div((int64_t)c.B * ceil_div(c.IH, S) * ceil_div(c.IW, S), (int64_t)64) * S * S;
+}
+
+int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, const ConvShape &c, hipStream_t s,
+               float *colsum_rows, int *nrows) {
+    if (nrows) *nrows = 0;
     if (c.stride > 1 && c.KH % c.stride == 0 && c.KW % c.stride == 0) {
         const int S = c.stride, KHp = c.KH / S, KWp = c.KW / S;
         if (c.IH % S == 0 && c.IW % S == 0 && pixel_major_ok(c, (int64_t)c.B * (c.IH / S) * (c.IW / S)) && KHp <= c.IH / S &&
@@ -465,7 +477,9 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
             // all S x S classes in one product: n = ((ph, pw), ci)
             const int IHp = c.IH / S, IWp = c.IW / S;
             const PixelMajor q{geom(c), 0, 0, IHp, IWp, KHp, KWp, 1, 0, 0, 0};
-            return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q}, (int64_t)c.B * IHp * IWp, S * S * c.Cin,
+            const int64_t Mq = (int64_t)c.B * IHp * IWp;
+            if (nrows && colsum_rows) *nrows = (int)(gemm_row_tiles(Mq, S * S * c.Cin, 1) * S * S);      // [tile][class][ci]
+            return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, colsum_rows}, Mq, S * S * c.Cin,
                                KHp * KWp * c.Cout, 1, s, "conv_dgrad");
         }
         for (int ph = 0; ph < S; ph++)
@@ -476,7 +490,7 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
                 const int K = KHp * KWp * c.Cout;
                 if (pixel_major_ok(c, M) && KHp <= IHp && KWp <= IWp) {
                     const PixelMajor q{geom(c), ph, pw, IHp, IWp, KHp, KWp, 0, 0, 0, 0};
-                    int rc = launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q}, M, c.Cin, K, 1, s, "conv_dgrad");
+                    int rc = launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, nullptr}, M, c.Cin, K, 1, s, "conv_dgrad");
                     if (rc) return rc;
                     continue;
                 }
@@ -490,9 +504,10 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
     const int K = c.KH * c.KW * c.Cout;
     if (c.stride == 1 && pixel_major_ok(c, M) && c.KH <= c.IH && c.KW <= c.IW) {
         const PixelMajor q{geom(c), 0, 0, c.IH, c.IW, c.KH, c.KW, 0, 0, 0, 0};
-        return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q}, M, c.Cin, K, 1, s, "conv_dgrad");
+        if (nrows && colsum_rows) *nrows = (int)gemm_row_tiles(M, c.Cin, 1);
+        return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, colsum_rows}, M, c.Cin, K, 1, s, "conv_dgrad");
     }
-    EpiActGrad ep{dX, c.Cin, Xact, c.Cin, ACT_RELU, 0};
+    EpiActGrad ep{dX, c.Cin, Xact, c.Cin, ACT_RELU, 0, nullptr};
     return launch_gemm(DgradCol{dY, geom(c)}, DgradW{W, geom(c)}, ep, M, c.Cin, K, 1, s, "conv_dgrad");
 }
 

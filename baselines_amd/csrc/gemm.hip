@@ -16,10 +16,11 @@ int fc_forward(const float *X, int ldx, const float *W, const float *b, float *Y
 }
 
 int fc_dgrad(const float *dY, int lddy, const float *W, int Kin, int N, const float *H, int ldh, int act,
-             float *dX, int lddx, int M, bool accumulate, hipStream_t s) {
+             float *dX, int lddx, int M, bool accumulate, hipStream_t s, float *colsum_tiles, int *ntiles) {
     RowMajor A{dY, lddy};
     Transposed B{W, N};   // B(k = n, j = kin) = W[kin][n]
-    EpiActGrad ep{dX, lddx, H, ldh, act, accumulate ? 1 : 0};
+    EpiActGrad ep{dX, lddx, H, ldh, act, accumulate ? 1 : 0, colsum_tiles};
+    if (ntiles) *ntiles = (int)gemm_row_tiles(M, Kin, 1);
     return launch_gemm(A, B, ep, M, Kin, N, 1, s, "fc_dgrad");
 }
 
@@ -92,8 +93,22 @@ int slab_bias_rows(const float *dY, int lddy, int64_t S, int Kin, int N, float *
     return check_launch("slab_colsum_kernel");
 }
 
+// dst[n] = sum over the S rows of rows[S, N], in a fixed order: up to 256 chunks of rows summed side by side into
+// scratch[chunks][N], then added
+int colsum_rows(const float *rows, int64_t S, int N, float *scratch, float *dst, hipStream_t s) {
+    if (S <= 0 || N <= 0) return 0;
+    int nchunks = (int)(ceil_div(S, (int64_t)64) < 256 ? ceil_div(S, (int64_t)64) : 256);
+    const int64_t klen = ceil_div(S, (int64_t)nchunks);
+    nchunks = (int)ceil_div(S, klen);
+    hipLaunchKernelGGL(slab_colsum_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)nchunks), dim3(256), 0, s, rows, (int64_t)N, S, N,
+                       klen, scratch, (int64_t)N, (int64_t)0);
+    int rc = check_launch("slab_colsum_kernel");
+    if (rc) return rc;
+    return reduce_slabs(scratch, nchunks, N, dst, false, s);
+}
+
 int fc_wgrad_slabs(const float *X, int ldx, const float *dY, int lddy, int64_t S, int Kin, int N,
-                   float *slabs, int max_slabs, int *nslabs, hipStream_t s) {
+                   float *slabs, int max_slabs, int *nslabs, hipStream_t s, bool bias_rows) {
     int n = wgrad_max_slabs(S, Kin, N);
     if (n > max_slabs) n = max_slabs;
     *nslabs = n;
@@ -102,7 +117,7 @@ int fc_wgrad_slabs(const float *X, int ldx, const float *dY, int lddy, int64_t S
     if (wgrad_bias_separately(Kin)) {
         TransposedOnes A{X, ldx, -1};    // no ones-row: rows 0 .. Kin-1 only
         int rc = launch_gemm(A, B, ep, Kin, N, S, n, s, "fc_wgrad");
-        if (rc) return rc;
+        if (rc || !bias_rows) return rc;
         return slab_bias_rows(dY, lddy, S, Kin, N, slabs, n, s);
     }
     TransposedOnes A{X, ldx, Kin};   // A(i = kin, k = sample) = X[sample][kin]; row Kin = 1
@@ -114,7 +129,7 @@ int fc_wgrad_slabs(const float *X, int ldx, const float *dY, int lddy, int64_t S
 constexpr int kReduceGroups = 16;
 __global__ __launch_bounds__(64 * kReduceGroups) void reduce_slabs_kernel(const float *__restrict__ slabs, int nslabs,
                                                                           int64_t size, float *__restrict__ dst,
-                                                                          int accumulate) {
+                                                                          int accumulate, int64_t stride) {
     __shared__ float part[kReduceGroups][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(64 * kReduceGroups) void reduce_slabs_kernel(const 
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int z = z0 + u * kReduceGroups;
-                x[u] = z < nslabs ? slabs[(int64_t)z * size + i] : 0.f;
+                x[u] = z < nslabs ? slabs[(int64_t)z * stride + i] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < U; u++) s += x[u];
@@ -142,10 +157,10 @@ __global__ __launch_bounds__(64 * kReduceGroups) void reduce_slabs_kernel(const 
     }
 }
 
-int reduce_slabs(const float *slabs, int nslabs, int64_t size, float *dst, bool accumulate, hipStream_t s) {
+int reduce_slabs(const float *slabs, int nslabs, int64_t size, float *dst, bool accumulate, hipStream_t s, int64_t stride) {
     if (size <= 0) return 0;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(size, 64)), dim3(64 * kReduceGroups), 0, s, slabs, nslabs,
-                       size, dst, accumulate ? 1 : 0);
+                       size, dst, accumulate ? 1 : 0, stride > 0 ? stride : size);
     return check_launch("reduce_slabs");
 }
 

@@ -48,6 +48,12 @@ struct tile_k : std::false_type {};
 template <class L>
 struct tile_k<L, std::enable_if_t<L::kTileK>> : std::true_type {};
 
+// an epilogue with `static constexpr bool kColSum = true` returns what it stored and has a `float *colsum` (null: off)
+template <class E, class = void>
+struct col_sum : std::false_type {};
+template <class E>
+struct col_sum<E, std::enable_if_t<E::kColSum>> : std::true_type {};
+
 // LDS row pitch: rows lh = 0 / 1 of an operand read must land on different bank halves (pitch = 32 mod 64)
 // when rows are written as vectors; the scalar path keeps the odd pitch that spreads its k-fast writes.
 // Vectors along k written with the k group as the fastest lane index (four lanes cover 64 contiguous bytes of one
@@ -361,13 +367,39 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     EpRow *rows = reinterpret_cast<EpRow *>(As);
     if (tid < BM) rows[tid] = ep.row(m0 + tid < M ? m0 + tid : M - 1, z);
     __syncthreads();
+    float csum[NB];          // column sums of what this thread stored (epilogues with kColSum)
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
         const int n = n0 + (wn * NB + nb) * 32 + li;
+        csum[nb] = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m0 + ml < M && n < N) ep(rows[ml], n, acc[nb][r]);
+            if (m0 + ml < M && n < N) {
+                if constexpr (col_sum<EP>::value) csum[nb] += ep(rows[ml], n, acc[nb][r]);
+                else ep(rows[ml], n, acc[nb][r]);
+            }
+        }
+    }
+    // The consumer of a gradient tensor wants its column sums too (the bias gradient of the layer it came out of):
+    // a tile's sums leave here, added in a fixed order (lane halves, then wave rows), one row of N per (row tile, slab),
+    // instead of a second pass over the tensor.
+    if constexpr (col_sum<EP>::value) {
+        if (ep.colsum) {
+            static_assert(WM * BN <= GEMM_BK * LDB, "tile sums must fit the B tile");
+            __syncthreads();
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) {
+                const float v = csum[nb] + __shfl_xor(csum[nb], 32, 64);
+                if (lh == 0) Bs[wm * BN + (wn * NB + nb) * 32 + li] = v;
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < N) {
+                float t = Bs[tid];
+#pragma unroll
+                for (int q = 1; q < WM; q++) t += Bs[q * BN + tid];
+                ep.colsum[((int64_t)blockIdx.x * gridDim.z + z) * N + n0 + tid] = t;
+            }
         }
     }
 }
@@ -384,6 +416,13 @@ inline int launch_gemm_v(const AL &a, const BL &b, const EP &ep, int64_t M, int 
     return check_launch(what);
 }
 
+// rows per tile launch_gemm takes for a product of M x N with nsplit slabs, and the number of row tiles that makes
+inline bool gemm_small_m(int64_t M, int N, int nsplit) {
+    // 64-row tiles for short operands, and wherever 128-row tiles would leave most of the 256 CUs without a workgroup
+    return M <= 64 || (M <= 512 && ceil_div(M, 128) * ceil_div(N, 64) * nsplit < 128);
+}
+inline int64_t gemm_row_tiles(int64_t M, int N, int nsplit) { return ceil_div(M, gemm_small_m(M, N, nsplit < 1 ? 1 : nsplit) ? 64 : 128); }
+
 template <class AL, class BL, class EP>
 inline int launch_gemm(const AL &a, const BL &b, const EP &ep, int64_t M, int N, int64_t K, int nsplit,
                        hipStream_t s, const char *what) {
@@ -391,8 +430,7 @@ inline int launch_gemm(const AL &a, const BL &b, const EP &ep, int64_t M, int N,
     if (nsplit < 1) nsplit = 1;
     int64_t klen = ceil_div(K > 0 ? K : 1, nsplit);
     klen = ceil_div(klen, GEMM_BK) * GEMM_BK;
-    // 64-row tiles for short operands, and wherever 128-row tiles would leave most of the 256 CUs without a workgroup
-    const bool small_m = M <= 64 || (M <= 512 && ceil_div(M, 128) * ceil_div(N, 64) * nsplit < 128);
+    const bool small_m = gemm_small_m(M, N, nsplit);
     const bool narrow = !small_m && N <= 32;        // half of a 64-column tile would multiply zeros
     const int BM = small_m ? 64 : 128, BN = narrow ? 32 : 64;
     const int64_t gx = ceil_div(M, BM);
@@ -513,6 +551,7 @@ struct EpiBiasAct {
     }
 };
 struct EpiActGrad {
+    static constexpr bool kColSum = true;
     struct Row { int64_t c, h; };
     float *C;
     int64_t ldc;
@@ -520,12 +559,14 @@ struct EpiActGrad {
     int64_t ldh;
     int act;
     int accumulate;
+    float *colsum;           // [row tiles][N] column sums of the stored values, or null
     __device__ Row row(int64_t m, int) const { return Row{m * ldc, m * ldh}; }
-    __device__ void operator()(const Row &r, int n, float v) const {
+    __device__ float operator()(const Row &r, int n, float v) const {
         if (H) v *= act_grad(H[r.h + n], act);
         float *d = C + r.c + n;
         if (accumulate) v += *d;
         *d = v;
+        return v;
     }
 };
 struct EpiSlab {

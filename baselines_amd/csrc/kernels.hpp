@@ -16,11 +16,15 @@ int fc_forward(const float *X, int ldx, const float *W, const float *b, float *Y
                int K, int act, bool accumulate, hipStream_t s);
 // dX[M,Kin] = (dY[M,N] W^T) * act'(H)   H = saved activation of the layer that produced X (or null)
 int fc_dgrad(const float *dY, int lddy, const float *W, int Kin, int N, const float *H, int ldh, int act,
-             float *dX, int lddx, int M, bool accumulate, hipStream_t s);
-// slabs[z][(Kin+1), N]: rows 0..Kin-1 = X^T dY, row Kin = column sums of dY (the bias gradient),
-// each over the z-th slice of the S sample rows.  Returns the number of slabs written in *nslabs.
+             float *dX, int lddx, int M, bool accumulate, hipStream_t s, float *colsum_tiles = nullptr,
+             int *ntiles = nullptr);
+//   colsum_tiles (optional): [*ntiles][Kin] column sums of dX per row tile — the bias gradient of the layer dX came
+//   out of, without a second pass over dX (add the rows with reduce_slabs)
+// slabs[z][(Kin+1), N]: rows 0..Kin-1 = X^T dY, row Kin = column sums of dY (the bias gradient; left unwritten with
+// bias_rows = false where it would take a pass of its own), each over the z-th slice of the S sample rows.
+// Returns the number of slabs written in *nslabs.
 int fc_wgrad_slabs(const float *X, int ldx, const float *dY, int lddy, int64_t S, int Kin, int N,
-                   float *slabs, int max_slabs, int *nslabs, hipStream_t s);
+                   float *slabs, int max_slabs, int *nslabs, hipStream_t s, bool bias_rows = true);
 int wgrad_max_slabs(int64_t S, int Kin, int N);
 // split-k partial products for few-row operands: parts[z][M, N] = X[:, k-slice z] W[k-slice z, :]
 int fc_forward_parts(const float *X, int ldx, const float *W, int M, int N, int K, int nparts, float *parts, hipStream_t s);
@@ -30,8 +34,10 @@ int fc_dgrad_parts(const float *dY, int lddy, const float *W, int Kin, int N, in
 bool wgrad_bias_separately(int Kin);
 // row Kin of every slab = column sums of dY over that slab's sample rows
 int slab_bias_rows(const float *dY, int lddy, int64_t S, int Kin, int N, float *slabs, int nslabs, hipStream_t s);
-// dst[i] (+)= sum_z slabs[z][i]
-int reduce_slabs(const float *slabs, int nslabs, int64_t size, float *dst, bool accumulate, hipStream_t s);
+// dst[n] = sum of the S rows of rows[S, N]; scratch: 256 N floats
+int colsum_rows(const float *rows, int64_t S, int N, float *scratch, float *dst, hipStream_t s);
+// dst[i] (+)= sum_z slabs[z * stride + i] for i < size (stride 0: slabs of `size` elements back to back)
+int reduce_slabs(const float *slabs, int nslabs, int64_t size, float *dst, bool accumulate, hipStream_t s, int64_t stride = 0);
 
 // ---- convolution as implicit GEMM (conv.hip) -------------------------------------------
 struct ConvShape {
@@ -42,10 +48,14 @@ int conv_forward(const void *X, bool x_u8, const float *W, const float *b, float
                  hipStream_t s);
 // slabs[z][(KH*KW*Cin+1), Cout] as fc_wgrad_slabs
 int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape &c, float *slabs,
-                     int max_slabs, int *nslabs, hipStream_t s);
+                     int max_slabs, int *nslabs, hipStream_t s, bool bias_rows = true);
 int conv_wgrad_max_slabs(const ConvShape &c);
 // dX[B,IH,IW,Cin] = conv_transpose(dY, W) * relu'(Xact)   (Xact = the layer's float32 input activation)
-int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, const ConvShape &c, hipStream_t s);
+//   colsum_rows (optional): on return *nrows rows of Cin column sums of dX (one per row tile and parity class), or
+//   *nrows = 0 when the route taken does not produce them; max_rows = conv_dgrad_colsum_rows(c)
+int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, const ConvShape &c, hipStream_t s,
+               float *colsum_rows = nullptr, int *nrows = nullptr);
+int64_t conv_dgrad_colsum_rows(const ConvShape &c);
 
 // ---- gather (gather.hip) ---------------------------------------------------------------
 // device address of this GPU's fault word (a static device array of the library; symbol lookup on the first call per

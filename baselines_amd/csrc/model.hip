@@ -328,6 +328,7 @@ struct CnnBuf {
     float *slabs;
     int max_slabs;
     double *loss_partial;
+    float *CS;                                 // per-tile column sums handed from an input-gradient product to the bias gradient
 };
 
 static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver &c, CnnBuf &w, bool grad) {
@@ -384,6 +385,13 @@ static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver 
     w.max_slabs = ms;
     w.slabs = c.take<float>(se);
     w.loss_partial = c.take<double>((int64_t)loss_partial_blocks(B) * 80);
+    {
+        const ConvShape c3 = conv_shape((int)B, k.h2, k.w2, 64, 3, 1, 64), c2 = conv_shape((int)B, k.h1, k.w1, 32, 4, 2, 64);
+        int64_t n = ceil_div(B, (int64_t)64) * k.flat;
+        if (conv_dgrad_colsum_rows(c3) * 64 > n) n = conv_dgrad_colsum_rows(c3) * 64;
+        if (conv_dgrad_colsum_rows(c2) * 32 > n) n = conv_dgrad_colsum_rows(c2) * 32;
+        w.CS = c.take<float>(n);
+    }
 }
 
 // conv trunk + fc1: X (uint8 NHWC) -> F [B, 512]
@@ -457,12 +465,18 @@ static int wgrad_into(const float *X, int ldx, const float *dY, int lddy, int64_
     return reduce_slabs(slabs, ns, (int64_t)(Kin + 1) * N, dst, false, s);
 }
 
+// bias_rows: `nbias` rows of Cout column sums of dY that the product which wrote dY left behind (its row tiles), or
+// null — then the bias gradient costs a pass of its own over dY
 static int conv_wgrad_into(const void *X, bool u8, const float *dY, const ConvShape &c, float *slabs, int max_slabs,
-                           float *dst, hipStream_t s) {
+                           float *dst, hipStream_t s, const float *bias_rows = nullptr, int nbias = 0) {
     int ns = 0;
-    int rc = conv_wgrad_slabs(X, u8, dY, c, slabs, max_slabs, &ns, s);
+    const int64_t K = (int64_t)c.KH * c.KW * c.Cin;
+    const bool given = bias_rows && nbias > 0 && wgrad_bias_separately((int)K);
+    int rc = conv_wgrad_slabs(X, u8, dY, c, slabs, max_slabs, &ns, s, !given);
     if (rc) return rc;
-    return reduce_slabs(slabs, ns, (int64_t)(c.KH * c.KW * c.Cin + 1) * c.Cout, dst, false, s);
+    if (!given) return reduce_slabs(slabs, ns, (K + 1) * c.Cout, dst, false, s);
+    if ((rc = reduce_slabs(slabs, ns, K * c.Cout, dst, false, s, (K + 1) * c.Cout))) return rc;
+    return colsum_rows(bias_rows, nbias, c.Cout, slabs, dst + K * c.Cout, s);        // the slabs are spent: scratch
 }
 
 static int cnn_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, const Layout &L, const float *p,
@@ -567,15 +581,24 @@ static int cnn_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
     }
     // fc1
     if ((rc = wgrad_into(w.Y3, k.flat, w.dF, 512, B, k.flat, 512, w.slabs, w.max_slabs, grads + L.off("fc1/w"), s))) return rc;
-    if ((rc = fc_dgrad(w.dF, 512, p + L.off("fc1/w"), k.flat, 512, w.Y3, k.flat, ACT_RELU, w.dY3, k.flat, (int)B, false, s))) return rc;
+    // Every product that writes a gradient tensor leaves that tensor's column sums per row tile in w.CS: they are the
+    // bias gradient of the layer below, which would otherwise read the whole tensor once more (PPO2HIP_BIAS_PASS=1 does).
+    const bool hand_on = !getenv("PPO2HIP_BIAS_PASS");
+    int nb = 0;
+    if ((rc = fc_dgrad(w.dF, 512, p + L.off("fc1/w"), k.flat, 512, w.Y3, k.flat, ACT_RELU, w.dY3, k.flat, (int)B, false, s,
+                       hand_on ? w.CS : nullptr, &nb))) return rc;
     // conv3, conv2, conv1
     const ConvShape c3 = conv_shape((int)B, k.h2, k.w2, 64, 3, 1, 64), c2 = conv_shape((int)B, k.h1, k.w1, 32, 4, 2, 64),
                     c1 = conv_shape((int)B, k.H, k.W, k.C, 8, 4, 32);
-    if ((rc = conv_wgrad_into(w.Y2, false, w.dY3, c3, w.slabs, w.max_slabs, grads + L.off("c3/w"), s))) return rc;
-    if ((rc = conv_dgrad(w.dY3, p + L.off("c3/w"), w.Y2, w.dY2, c3, s))) return rc;
-    if ((rc = conv_wgrad_into(w.Y1, false, w.dY2, c2, w.slabs, w.max_slabs, grads + L.off("c2/w"), s))) return rc;
-    if ((rc = conv_dgrad(w.dY2, p + L.off("c2/w"), w.Y1, w.dY1, c2, s))) return rc;
-    if ((rc = conv_wgrad_into(w.X, true, w.dY1, c1, w.slabs, w.max_slabs, grads + L.off("c1/w"), s))) return rc;
+    // dY3 rows are (h, w, c) with c fastest: a tile's row of `flat` sums is h3 w3 rows of 64
+    if ((rc = conv_wgrad_into(w.Y2, false, w.dY3, c3, w.slabs, w.max_slabs, grads + L.off("c3/w"), s, hand_on ? w.CS : nullptr,
+                              nb * k.h3 * k.w3))) return rc;
+    nb = 0;
+    if ((rc = conv_dgrad(w.dY3, p + L.off("c3/w"), w.Y2, w.dY2, c3, s, hand_on ? w.CS : nullptr, &nb))) return rc;
+    if ((rc = conv_wgrad_into(w.Y1, false, w.dY2, c2, w.slabs, w.max_slabs, grads + L.off("c2/w"), s, hand_on ? w.CS : nullptr, nb))) return rc;
+    nb = 0;
+    if ((rc = conv_dgrad(w.dY2, p + L.off("c2/w"), w.Y1, w.dY1, c2, s, hand_on ? w.CS : nullptr, &nb))) return rc;
+    if ((rc = conv_wgrad_into(w.X, true, w.dY1, c1, w.slabs, w.max_slabs, grads + L.off("c1/w"), s, hand_on ? w.CS : nullptr, nb))) return rc;
     return 0;
 }
 
