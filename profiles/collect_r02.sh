@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 profile collection, run on the GPU box from the repo root:  bash profiles/collect_r02.sh [workloads...]
+# Profile collection for the files profiles/r02_*, run on the GPU box from the repo root:  bash profiles/collect_r02.sh [workloads...]
 # Each pass is its own rocprofv3 run (kernel trace + stats; FETCH_SIZE; WRITE_SIZE); the summaries land in gpurun_out/
 # and are copied into profiles/ by hand.
 set -u
