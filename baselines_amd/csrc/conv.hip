@@ -58,6 +58,11 @@ __device__ inline void tap_advance(const ConvGeom &g, TapOff &t, int d) {
     }
 }
 
+// uint8 observations load as the integers they are; the 1/255 of the network's input scaling
+// (baselines/common/models.py:22) multiplies the finished product in the epilogue, once per output element instead of
+// once per loaded tap.
+constexpr float kU8Scale = 1.0f / 255.0f;
+
 template <bool U8>
 struct Im2col {   // A(m, k)
     static constexpr bool kInnerFast = true;
@@ -70,7 +75,7 @@ struct Im2col {   // A(m, k)
     __device__ void advance_col(Col &c, int d) const { tap_advance(g, c, d); }
     __device__ float at(const Row &r, const Col &c) const { return at_off(r, c.off); }
     __device__ float at_off(int64_t r, int off) const {
-        if (U8) return (float)((const uint8_t *)x)[r + off] * (1.0f / 255.0f);
+        if (U8) return (float)((const uint8_t *)x)[r + off];
         return ((const float *)x)[r + off];
     }
     // 16 bytes per load: sixteen uint8 taps, or four float taps, of one kernel row (kw, ci run contiguously)
@@ -89,7 +94,7 @@ struct Im2col {   // A(m, k)
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) o[4 * q + j] = (float)((w[q] >> (8 * j)) & 0xffu) * (1.0f / 255.0f);
+                for (int j = 0; j < 4; j++) o[4 * q + j] = (float)((w[q] >> (8 * j)) & 0xffu);
         } else {
             const float4 v = *(const float4 *)((const float *)x + r + c);
             o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -98,7 +103,7 @@ struct Im2col {   // A(m, k)
 };
 
 template <bool U8>
-struct Im2colT {   // A(i = k, kk = m), row `ones_row` = 1
+struct Im2colT {   // A(i = k, kk = m), row `ones_row` = 1 after the epilogue's scaling
     static constexpr bool kInnerFast = false;
     typedef int Row;          // tap offset, or -1 for the row of ones
     typedef PatchRow Col;
@@ -126,7 +131,7 @@ struct Im2colT {   // A(i = k, kk = m), row `ones_row` = 1
         }
         p.base = (((int64_t)p.b * g.IH + p.oh * g.S) * g.IW + p.ow * g.S) * g.Cin;
     }
-    __device__ float at(const Row &r, const Col &p) const { return r < 0 ? 1.f : c.at_off(p.base, r); }
+    __device__ float at(const Row &r, const Col &p) const { return r < 0 ? (U8 ? 255.f : 1.f) : c.at_off(p.base, r); }
     static constexpr int kVec = Im2col<U8>::kVec;
     int vec_width() const { return ones_row < 0 ? c.vec_width() : 1; }     // no row of ones among wide loads
     __device__ void at_vec(const Row &r, const Col &p, float (&o)[kVec]) const { c.at_vec_off(p.base, r, o); }
@@ -352,7 +357,7 @@ int conv_forward(const void *X, bool x_u8, const float *W, const float *b, float
     const int64_t M = (int64_t)c.B * c.OH * c.OW;
     const int K = c.KH * c.KW * c.Cin;
     RowMajor Bm{W, c.Cout};
-    EpiBiasAct ep{Y, c.Cout, b, ACT_RELU, 0};
+    EpiBiasAct ep{Y, c.Cout, b, ACT_RELU, 0, x_u8 ? kU8Scale : 1.f};
     if (x_u8) return launch_gemm(Im2col<true>{X, geom(c)}, Bm, ep, M, c.Cout, K, 1, s, "conv_forward");
     return launch_gemm(Im2col<false>{X, geom(c)}, Bm, ep, M, c.Cout, K, 1, s, "conv_forward");
 }
@@ -370,7 +375,7 @@ int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape 
     if (n > max_slabs) n = max_slabs;
     *nslabs = n;
     RowMajor Bm{dY, c.Cout};
-    EpiSlab ep{slabs, c.Cout, (int64_t)(K + 1) * c.Cout};
+    EpiSlab ep{slabs, c.Cout, (int64_t)(K + 1) * c.Cout, x_u8 ? kU8Scale : 1.f};
     const bool sep = wgrad_bias_separately(K);         // ones-row only where it does not stand in the way of wide loads
     const int64_t ones = sep ? -1 : K, rows = sep ? K : K + 1;
     int rc;

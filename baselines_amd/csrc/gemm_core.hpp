@@ -542,8 +542,10 @@ struct EpiBiasAct {
     const float *bias;
     int act;
     int accumulate;
+    float scale = 1.f;       // of the product, before the bias (operands that load unscaled integers)
     __device__ Row row(int64_t m, int) const { return m * ldc; }
     __device__ void operator()(const Row &r, int n, float v) const {
+        v *= scale;
         if (bias) v += bias[n];
         float *d = C + r + n;
         if (accumulate) v += *d;
@@ -574,8 +576,9 @@ struct EpiSlab {
     float *C;
     int64_t ldc;
     int64_t zstride;
+    float scale = 1.f;
     __device__ Row row(int64_t m, int z) const { return z * zstride + m * ldc; }
-    __device__ void operator()(const Row &r, int n, float v) const { C[r + n] = v; }
+    __device__ void operator()(const Row &r, int n, float v) const { C[r + n] = v * scale; }
 };
 
 }  // namespace ppo2hip
