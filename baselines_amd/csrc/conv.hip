@@ -78,21 +78,23 @@ struct Im2col {   // A(m, k)
         if (U8) return (float)((const uint8_t *)x)[r + off];
         return ((const float *)x)[r + off];
     }
-    // 16 bytes per load: sixteen uint8 taps, or four float taps, of one kernel row (kw, ci run contiguously)
-    static constexpr int kVec = U8 ? 16 : 4;
+    // one load: eight uint8 taps (8 bytes), or four float taps (16 bytes), of one kernel row (kw, ci run contiguously).
+    // Eight, not sixteen, bytes: a 128-row tile is then 256 loads per slab, one for every thread, where sixteen-byte
+    // loads would leave the conversion and the LDS writes to half of the workgroup's waves.
+    static constexpr int kVec = U8 ? 8 : 4;
     int vec_width() const {
-        const int esz = U8 ? 1 : 4;
+        const int esz = U8 ? 1 : 4, bytes = U8 ? 8 : 16;
         const bool ok = aligned16(x) && (g.KW * g.Cin) % kVec == 0 && (g.Cin * esz) % 4 == 0 &&
-                        (g.IW * g.Cin * esz) % 16 == 0 && (g.S * g.Cin * esz) % 16 == 0;
+                        (g.IW * g.Cin * esz) % bytes == 0 && (g.S * g.Cin * esz) % bytes == 0;
         return ok ? kVec : 1;
     }
     __device__ void at_vec(const Row &r, const Col &c, float (&o)[kVec]) const { at_vec_off(r, c.off, o); }
     __device__ void at_vec_off(int64_t r, int c, float (&o)[kVec]) const {
         if constexpr (U8) {
-            const uint4 v = *(const uint4 *)((const uint8_t *)x + r + c);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const uint2 v = *(const uint2 *)((const uint8_t *)x + r + c);
+            const uint32_t w[2] = {v.x, v.y};
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < 2; q++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) o[4 * q + j] = (float)((w[q] >> (8 * j)) & 0xffu);
         } else {
@@ -356,6 +358,7 @@ int conv_forward(const void *X, bool x_u8, const float *W, const float *b, float
                  hipStream_t s) {
     const int64_t M = (int64_t)c.B * c.OH * c.OW;
     const int K = c.KH * c.KW * c.Cin;
+    if (x_u8 && conv_u8_forward_ok(X, c)) return conv_u8_forward(X, W, b, Y, c, s);
     RowMajor Bm{W, c.Cout};
     EpiBiasAct ep{Y, c.Cout, b, ACT_RELU, 0, x_u8 ? kU8Scale : 1.f};
     if (x_u8) return launch_gemm(Im2col<true>{X, geom(c)}, Bm, ep, M, c.Cout, K, 1, s, "conv_forward");

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     // m-contiguous A read sixteen at a time (uint8 taps): lanes run along k, so that a wave's sixteen-byte loads are
     // consecutive pixels (contiguous in memory for a stride of four 4-channel pixels) and its four 16-byte LDS writes per
     // lane land on sixteen different rows, which the 36-mod-64 pitch spreads over all banks
-    constexpr bool A_K_LANES = !AL::kInnerFast && AV == GEMM_BK;
+    constexpr bool A_K_LANES = !AL::kInnerFast && AV >= 8;
     constexpr int LDA = lds_pitch(BM, AV == 1 ? 0 : (A_KG_FAST || A_K_LANES) ? 2 : 1), LDB = lds_pitch(BN, BV == 1 ? 0 : BL::kInnerFast ? 1 : 2);
     // element-wise: elements per thread; vector: tasks (one wide load each) per thread
     constexpr int A_TASKS_ALL = BM * GEMM_BK / AV, B_TASKS_ALL = BN * GEMM_BK / BV;

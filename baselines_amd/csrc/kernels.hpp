@@ -46,6 +46,9 @@ struct ConvShape {
 // Y[B,OH,OW,Cout] = relu(conv(X) + b); X float32 NHWC, or uint8 NHWC scaled by 1/255 (x_u8)
 int conv_forward(const void *X, bool x_u8, const float *W, const float *b, float *Y, const ConvShape &c,
                  hipStream_t s);
+// the uint8 layer on the bf16 matrix pipe with float32-exact products (8 x 8 kernels of 32-byte rows, 32 channels)
+bool conv_u8_forward_ok(const void *X, const ConvShape &c);
+int conv_u8_forward(const void *X, const float *W, const float *b, float *Y, const ConvShape &c, hipStream_t s);
 // slabs[z][(KH*KW*Cin+1), Cout] as fc_wgrad_slabs
 int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape &c, float *slabs,
                      int max_slabs, int *nslabs, hipStream_t s, bool bias_rows = true);
