@@ -374,6 +374,7 @@ int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape 
                      int *nslabs, hipStream_t s, bool bias_rows) {
     const int64_t M = (int64_t)c.B * c.OH * c.OW;
     const int K = c.KH * c.KW * c.Cin;
+    if (x_u8 && conv_u8_wgrad_ok(X, dY, c)) return conv_u8_wgrad_slabs(X, dY, c, slabs, max_slabs, nslabs, s, bias_rows);
     int n = conv_wgrad_max_slabs(c);
     if (n > max_slabs) n = max_slabs;
     *nslabs = n;

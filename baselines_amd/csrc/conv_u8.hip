@@ -162,4 +162,211 @@ int conv_u8_forward(const void *X, const float *W, const float *b, float *Y, con
     return check_launch("conv_u8_forward");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layer: dW[tap][co] = (1/255) sum over pixels of x[pixel][tap] dY[pixel][co], again with exact
+// bf16 products — here the float32 operand that is cut into three pieces is dY.
+//
+// The sum runs over pixels, the slow index of both operands in memory, so both pass through LDS once per image:
+//   * the image itself, as the bytes it is (28 KB for 84 x 84 x 4; no im2col copy): lane (tap r, half h) of the A operand
+//     gathers its eight pixels' bytes with ds_read_u8 — a group of eight pixels is a 4 (ow) x 2 (oh) block, so the eight
+//     addresses are two bases plus immediates, and the 32 lanes of a half read 32 consecutive bytes (no bank conflict);
+//   * dY, cut up on the way in: thread (co, group) takes its eight pixels' values, splits them and writes three 16-byte
+//     fragments [piece][group][co] — exactly what lane (co, h) of the B operand reads back with one ds_read_b128.
+//     The same values give the bias gradient (column sums of dY) on the side.
+// Eight waves, one per kernel row: wave kh holds dW[kh, :, :, :] (32 taps x 32 channels, 16 accumulator registers) for
+// the whole launch; a workgroup walks images z, z + gridDim.x, ... and leaves one slab [K + 1][32] for the fixed-order
+// reduction the other weight gradients use.  Loads of the next image (taps and dY) fly during the products of this one.
+namespace u8c {
+constexpr int kWgThreads = 512;
+constexpr int kXR = 4;            // 16-byte image loads per thread: images up to 32 KB
+constexpr int kNR = 4;            // dY tasks per thread: up to 64 pixel groups (512 pixels) per image
+struct WGeom {
+    int IH, IW, Cin, OH, OW, S;
+    int img_bytes, row_bytes, G, Gpad, Q;     // Q = OW / 4 groups per pair of output rows
+};
+}  // namespace u8c
+
+__global__ __launch_bounds__(u8c::kWgThreads) void conv_u8_wgrad_kernel(const uint8_t *__restrict__ X,
+                                                                        const float *__restrict__ dY,
+                                                                        float *__restrict__ slabs, u8c::WGeom g, int B,
+                                                                        int K, float scale, int bias_rows) {
+    using namespace u8c;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *ximg = smem;                                                    // [img_bytes] (+ slack to a multiple of 16)
+    uint4 *pimg = (uint4 *)(smem + ((g.img_bytes + 15) & ~15));              // [3][Gpad][32] fragments
+    const int tid = threadIdx.x, lane = tid & 63, kh = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int co = tid & 31;
+
+    // the padding group of an odd group count multiplies as zero
+    for (int t = tid; t < 3 * (g.Gpad - g.G) * 32; t += kWgThreads) {
+        const int p = t / ((g.Gpad - g.G) * 32), q = t - p * (g.Gpad - g.G) * 32;
+        pimg[(p * g.Gpad + g.G) * 32 + q] = make_uint4(0u, 0u, 0u, 0u);
+    }
+
+    uint4 xr[kXR];
+    float dyr[kNR][8];
+    // task i of this thread: group tid / 32 + 16 i, channel co; its pixels (2 ohp + dy, 4 owq + dx), jj = 4 dy + dx
+    int dyoff[kNR];
+#pragma unroll
+    for (int i = 0; i < kNR; i++) {
+        const int grp = (tid >> 5) + 16 * i;
+        const int ohp = grp / g.Q, owq = grp - ohp * g.Q;
+        dyoff[i] = grp < g.G ? ((2 * ohp) * g.OW + 4 * owq) * kCout + co : -1;
+    }
+    auto prefetch = [&](int b) {
+        const uint4 *src = (const uint4 *)(X + (int64_t)b * g.img_bytes);
+#pragma unroll
+        for (int i = 0; i < kXR; i++)
+            if ((tid + i * kWgThreads) * 16 < g.img_bytes) xr[i] = src[tid + i * kWgThreads];
+        const float *dsrc = dY + (int64_t)b * g.OH * g.OW * kCout;
+#pragma unroll
+        for (int i = 0; i < kNR; i++)
+            if (dyoff[i] >= 0) {
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) dyr[i][jj] = dsrc[dyoff[i] + ((jj >> 2) * g.OW + (jj & 3)) * kCout];
+            }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    float bsum = 0.f;
+
+    int b = blockIdx.x;
+    if (b < B) prefetch(b);
+    for (; b < B; b += gridDim.x) {
+        // ---- phase A: this image's bytes and cut-up dY into LDS -------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < kXR; i++)
+            if ((tid + i * kWgThreads) * 16 < g.img_bytes) ((uint4 *)ximg)[tid + i * kWgThreads] = xr[i];
+#pragma unroll
+        for (int i = 0; i < kNR; i++)
+            if (dyoff[i] >= 0) {
+                unsigned hi[8], mid[8], lo[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    const float w = dyr[i][jj];
+                    bsum += w;
+                    hi[jj] = __float_as_uint(w) & 0xffff0000u;
+                    const float r1 = w - __uint_as_float(hi[jj]);
+                    mid[jj] = __float_as_uint(r1) & 0xffff0000u;
+                    lo[jj] = __float_as_uint(r1 - __uint_as_float(mid[jj]));
+                }
+                uint4 *dst = pimg + ((tid >> 5) + 16 * i) * 32 + co;
+                dst[0] = make_uint4(pack_hi16(hi[0], hi[1]), pack_hi16(hi[2], hi[3]), pack_hi16(hi[4], hi[5]), pack_hi16(hi[6], hi[7]));
+                dst[g.Gpad * 32] = make_uint4(pack_hi16(mid[0], mid[1]), pack_hi16(mid[2], mid[3]), pack_hi16(mid[4], mid[5]), pack_hi16(mid[6], mid[7]));
+                dst[2 * g.Gpad * 32] = make_uint4(pack_hi16(lo[0], lo[1]), pack_hi16(lo[2], lo[3]), pack_hi16(lo[4], lo[5]), pack_hi16(lo[6], lo[7]));
+            }
+        __syncthreads();
+        if (b + (int)gridDim.x < B) prefetch(b + gridDim.x);
+
+        // ---- phase B: groups 2 kb + h, two per product step ---------------------------------------------------------
+        int ohp = 0, owq = h;              // group h of step 0 (Q >= 2)
+        auto fetch_bytes = [&](unsigned (&v)[8]) {
+            const uint8_t *p0 = ximg + (8 * ohp + kh) * g.row_bytes + 64 * owq + r;
+            const uint8_t *p1 = p0 + 4 * g.row_bytes;
+#pragma unroll
+            for (int dx = 0; dx < 4; dx++) {
+                v[dx] = p0[16 * dx];
+                v[4 + dx] = p1[16 * dx];
+            }
+        };
+        auto advance = [&]() {
+            owq += 2;
+            if (owq >= g.Q) { owq -= g.Q; ohp++; }
+        };
+        unsigned xb[2][8];
+        uint4 wf[2][3];
+        fetch_bytes(xb[0]);
+#pragma unroll
+        for (int p = 0; p < 3; p++) wf[0][p] = pimg[(p * g.Gpad + h) * 32 + r];
+        const int nkb = g.Gpad >> 1;
+        for (int kb = 0; kb < nkb; kb += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; par++) {
+                if (kb + par < nkb) {
+                    advance();
+                    if (kb + par + 1 < nkb) {
+                        fetch_bytes(xb[par ^ 1]);
+#pragma unroll
+                        for (int p = 0; p < 3; p++) wf[par ^ 1][p] = pimg[(p * g.Gpad + 2 * (kb + par + 1) + h) * 32 + r];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    unsigned o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        o[q] = pack_hi16(__float_as_uint((float)xb[par][2 * q]), __float_as_uint((float)xb[par][2 * q + 1]));
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
+#pragma unroll
+                    for (int p = 2; p >= 0; p--)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, wf[par][p]), acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- this workgroup's slab: rows kh 32 + tap, then the bias row --------------------------------------------------
+    float *slab = slabs + (int64_t)blockIdx.x * (K + 1) * kCout;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int tap = (e & 3) + 8 * (e >> 2) + 4 * h;
+        slab[(kh * 32 + tap) * kCout + r] = acc[e] * scale;
+    }
+    if (bias_rows) {
+        float *red = (float *)smem;             // the images are spent
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < kCout) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < kWgThreads / kCout; q++) t += red[q * kCout + tid];
+            slab[K * kCout + tid] = t;
+        }
+    }
+}
+
+static size_t conv_u8_wgrad_lds(const ConvShape &c) {
+    const int G = c.OH * c.OW / 8, Gpad = (G + 1) & ~1;
+    const size_t img = ((size_t)c.IH * c.IW * c.Cin + 15) & ~(size_t)15;
+    // the padding group's byte reads may run a few image rows past the image: they land in the fragment area
+    return img + (size_t)3 * Gpad * 32 * 16;
+}
+
+bool conv_u8_wgrad_ok(const void *X, const float *dY, const ConvShape &c) {
+    static const bool plain = getenv("PPO2HIP_CONV_U8_PLAIN") != nullptr;
+    if (plain) return false;
+    const int64_t img = (int64_t)c.IH * c.IW * c.Cin;
+    const int G = c.OH * c.OW / 8;
+    return c.Cout == u8c::kCout && c.KH == 8 && c.KW * c.Cin == 32 && c.stride * c.Cin == 16 && ((uintptr_t)X & 15) == 0 &&
+           img % 16 == 0 && img <= (int64_t)u8c::kXR * u8c::kWgThreads * 16 && c.OW % 4 == 0 && c.OH % 2 == 0 && c.OW >= 8 &&
+           G <= 16 * u8c::kNR && conv_u8_wgrad_lds(c) <= 150 * 1024 && c.B > 0 && dY != nullptr;
+}
+
+int conv_u8_wgrad_slabs(const void *X, const float *dY, const ConvShape &c, float *slabs, int max_slabs, int *nslabs,
+                        hipStream_t s, bool bias_rows) {
+    using namespace u8c;
+    int n = c.B < 256 ? c.B : 256;             // one workgroup (105 KB of LDS for 84 x 84 x 4) per CU
+    if (n > max_slabs) n = max_slabs;
+    if (n < 1) n = 1;
+    *nslabs = n;
+    WGeom g;
+    g.IH = c.IH; g.IW = c.IW; g.Cin = c.Cin; g.OH = c.OH; g.OW = c.OW; g.S = c.stride;
+    g.img_bytes = c.IH * c.IW * c.Cin; g.row_bytes = c.IW * c.Cin;
+    g.G = c.OH * c.OW / 8; g.Gpad = (g.G + 1) & ~1; g.Q = c.OW / 4;
+    const int K = c.KH * c.KW * c.Cin;
+    const size_t lds = conv_u8_wgrad_lds(c);
+    // per device, and cheap: asked for on every call rather than remembered per device
+    if (hipFuncSetAttribute((const void *)conv_u8_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        set_error("conv_u8_wgrad: cannot raise the dynamic LDS limit");
+        return PPO2HIP_EINVAL;
+    }
+    hipLaunchKernelGGL(conv_u8_wgrad_kernel, dim3(n), dim3(kWgThreads), lds, s, (const uint8_t *)X, dY, slabs, g, c.B, K,
+                       1.0f / 255.0f, bias_rows ? 1 : 0);
+    return check_launch("conv_u8_wgrad");
+}
+
 }  // namespace ppo2hip

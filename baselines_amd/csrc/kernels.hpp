@@ -49,6 +49,9 @@ int conv_forward(const void *X, bool x_u8, const float *W, const float *b, float
 // the uint8 layer on the bf16 matrix pipe with float32-exact products (8 x 8 kernels of 32-byte rows, 32 channels)
 bool conv_u8_forward_ok(const void *X, const ConvShape &c);
 int conv_u8_forward(const void *X, const float *W, const float *b, float *Y, const ConvShape &c, hipStream_t s);
+bool conv_u8_wgrad_ok(const void *X, const float *dY, const ConvShape &c);
+int conv_u8_wgrad_slabs(const void *X, const float *dY, const ConvShape &c, float *slabs, int max_slabs, int *nslabs,
+                        hipStream_t s, bool bias_rows);
 // slabs[z][(KH*KW*Cin+1), Cout] as fc_wgrad_slabs
 int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape &c, float *slabs,
                      int max_slabs, int *nslabs, hipStream_t s, bool bias_rows = true);
