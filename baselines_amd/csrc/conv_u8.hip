@@ -50,23 +50,24 @@ __global__ __launch_bounds__(u8c::kThreads, 3) void conv_u8_forward_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    // first tile's taps go out before the weights are cut up
-    uint4 raw[DS];
-    auto load_tile = [&](int64_t tile) {
-        int64_t m = tile * 128 + wave * 32 + r;
-        m = m < M ? m : M - 1;
-        const int ohw = g.OH * g.OW;
-        const int64_t b = m / ohw;
-        const int rem = (int)(m - b * ohw);
-        const int oh = rem / g.OW, ow = rem - oh * g.OW;
-        const uint8_t *p = X + ((b * g.IH + oh * g.S) * g.IW + ow * g.S) * g.Cin + 16 * h;
+    // first tile's taps go out before the weights are cut up; two register sets, so that a tile's loads have the whole
+    // of the tile before it to arrive in
+    uint4 raw0[DS], raw1[DS];
+    auto load_tile = [&](int64_t tile, uint4 (&raw)[DS]) {
+        int64_t mm = tile * 128 + wave * 32 + r;
+        mm = mm < M ? mm : M - 1;
+        const unsigned m = (unsigned)mm;                     // M < 2^31 (host)
+        const unsigned ohw = (unsigned)(g.OH * g.OW);
+        const unsigned b = m / ohw, rem = m - b * ohw;
+        const unsigned oh = rem / (unsigned)g.OW, ow = rem - oh * (unsigned)g.OW;
+        const uint8_t *p = X + (((int64_t)b * g.IH + oh * g.S) * g.IW + ow * g.S) * g.Cin + 16 * h;
 #pragma unroll
         for (int kh = 0; kh < KH; kh++)
 #pragma unroll
             for (int c = 0; c < CPR; c++) raw[kh * CPR + c] = *(const uint4 *)(p + (int64_t)kh * g.IW * g.Cin + 32 * c);
     };
     int64_t tile = blockIdx.x;
-    if (tile < ntiles) load_tile(tile);
+    if (tile < ntiles) load_tile(tile, raw0);
 
     // ---- weight image: task = eight consecutive taps of one output channel ------------------------------------
     for (int t = tid; t < (K / 8) * kCout; t += kThreads) {
@@ -91,56 +92,67 @@ __global__ __launch_bounds__(u8c::kThreads, 3) void conv_u8_forward_kernel(const
     const float bco = bias ? bias[r] : 0.f;
     __syncthreads();
 
-    for (; tile < ntiles; tile += gridDim.x) {
-        // ---- bytes -> bf16 fragments (cvt_f32_ubyte, then the upper halves of two floats side by side) -------
-        uint4 frag[DS][2];
+    // bytes -> bf16 fragments of one 32-tap run (cvt_f32_ubyte, then the upper halves of two floats side by side)
+    auto convert = [&](const uint4 &v, uint4 (&f)[2]) {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int d = 0; d < DS; d++) {
-            const unsigned w[4] = {raw[d].x, raw[d].y, raw[d].z, raw[d].w};
+        for (int u = 0; u < 2; u++) {
+            unsigned o[4];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                unsigned o[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const unsigned src = w[2 * u + (q >> 1)];
-                    const float f0 = (float)((src >> (16 * (q & 1))) & 0xffu);
-                    const float f1 = (float)((src >> (16 * (q & 1) + 8)) & 0xffu);
-                    o[q] = pack_hi16(__float_as_uint(f0), __float_as_uint(f1));
-                }
-                frag[d][u] = make_uint4(o[0], o[1], o[2], o[3]);
+            for (int q = 0; q < 4; q++) {
+                const unsigned src = w[2 * u + (q >> 1)];
+                const float f0 = (float)((src >> (16 * (q & 1))) & 0xffu);
+                const float f1 = (float)((src >> (16 * (q & 1) + 8)) & 0xffu);
+                o[q] = pack_hi16(__float_as_uint(f0), __float_as_uint(f1));
             }
+            f[u] = make_uint4(o[0], o[1], o[2], o[3]);
         }
-        // ---- the next tile's taps fly while this one multiplies ------------------------------------------------
+    };
+    // one tile from the register set `cur` while the next tile's loads land in `nxt`; the conversion of run d + 1 is
+    // independent vector work between the dependent products of run d
+    auto do_tile = [&](uint4 (&cur)[DS], uint4 (&nxt)[DS]) {
         const int64_t next = tile + gridDim.x;
-        if (next < ntiles) load_tile(next);
-
+        if (next < ntiles) load_tile(next, nxt);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[e] = 0.f;
-        uint4 wf[2][3];         // weight fragments one k-step ahead of the products that take them
+        uint4 frag[2][2];
+        convert(cur[0], frag[0]);
 #pragma unroll
-        for (int p = 0; p < 3; p++) wf[0][p] = wimg[p * 64 + lane];
+        for (int d = 0; d < DS; d++) {
+            uint4 wf[2][3];
 #pragma unroll
-        for (int du = 0; du < 2 * DS; du++) {
-            if (du + 1 < 2 * DS) {
+            for (int u = 0; u < 2; u++)
 #pragma unroll
-                for (int p = 0; p < 3; p++) wf[(du + 1) & 1][p] = wimg[((du + 1) * 3 + p) * 64 + lane];
+                for (int p = 0; p < 3; p++) wf[u][p] = wimg[((d * 2 + u) * 3 + p) * 64 + lane];
+            if (d + 1 < DS) convert(cur[d + 1], frag[(d + 1) & 1]);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, frag[d & 1][u]);
+#pragma unroll
+                for (int p = 2; p >= 0; p--)        // small pieces first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, wf[u][p]), acc, 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 a = __builtin_bit_cast(bf16x8, frag[du >> 1][du & 1]);
-#pragma unroll
-            for (int p = 2; p >= 0; p--)        // small pieces first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, wf[du & 1][p]), acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);      // one run's reads, conversion and products at a time in flight
         }
         // ---- epilogue: rows (e & 3) + 8 (e >> 2) + 4 h of the wave's 32 pixels, column r = output channel --------
         const int64_t m0 = tile * 128 + wave * 32;
+        float *y = Y + (m0 + 4 * h) * kCout + r;
+        if (m0 + 32 <= M) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int64_t m = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float v = acc[e] * scale + bco;
-            if (m < M) Y[m * kCout + r] = v > 0.f ? v : 0.f;
+            for (int e = 0; e < 16; e++) y[((e & 3) + 8 * (e >> 2)) * kCout] = fmaxf(fmaf(acc[e], scale, bco), 0.f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                if (m0 + (e & 3) + 8 * (e >> 2) + 4 * h < M) y[((e & 3) + 8 * (e >> 2)) * kCout] = fmaxf(fmaf(acc[e], scale, bco), 0.f);
         }
+    };
+    while (tile < ntiles) {
+        do_tile(raw0, raw1);
+        tile += gridDim.x;
+        if (tile >= ntiles) break;
+        do_tile(raw1, raw0);
+        tile += gridDim.x;
     }
 }
 
@@ -148,7 +160,7 @@ bool conv_u8_forward_ok(const void *X, const ConvShape &c) {
     static const bool plain = getenv("PPO2HIP_CONV_U8_PLAIN") != nullptr;
     if (plain) return false;
     return c.Cout == u8c::kCout && c.KH == 8 && c.KW * c.Cin == 32 && ((uintptr_t)X & 15) == 0 &&
-           (c.stride * c.Cin) % 16 == 0 && (c.IW * c.Cin) % 16 == 0 && ((int64_t)c.IH * c.IW * c.Cin) % 16 == 0 && c.B > 0;
+           (int64_t)c.B * c.OH * c.OW < 0x7fffffffll && (c.stride * c.Cin) % 16 == 0 && (c.IW * c.Cin) % 16 == 0 && ((int64_t)c.IH * c.IW * c.Cin) % 16 == 0 && c.B > 0;
 }
 
 int conv_u8_forward(const void *X, const float *W, const float *b, float *Y, const ConvShape &c, hipStream_t s) {
@@ -168,9 +180,10 @@ int conv_u8_forward(const void *X, const float *W, const float *b, float *Y, con
 // bf16 products — here the float32 operand that is cut into three pieces is dY.
 //
 // The sum runs over pixels, the slow index of both operands in memory, so both pass through LDS once per image:
-//   * the image itself, as the bytes it is (28 KB for 84 x 84 x 4; no im2col copy): lane (tap r, half h) of the A operand
-//     gathers its eight pixels' bytes with ds_read_u8 — a group of eight pixels is a 4 (ow) x 2 (oh) block, so the eight
-//     addresses are two bases plus immediates, and the 32 lanes of a half read 32 consecutive bytes (no bank conflict);
+//   * the image itself, converted to bf16 once (56 KB for 84 x 84 x 4; no im2col copy): lane (tap r, half h) of the A
+//     operand gathers its eight pixels' values with 16-bit reads — a group of eight pixels is a 4 (ow) x 2 (oh) block, so
+//     the eight addresses are two bases plus immediates, and the 32 lanes of a half read 64 consecutive bytes (no bank
+//     conflict);
 //   * dY, cut up on the way in: thread (co, group) takes its eight pixels' values, splits them and writes three 16-byte
 //     fragments [piece][group][co] — exactly what lane (co, h) of the B operand reads back with one ds_read_b128.
 //     The same values give the bias gradient (column sums of dY) on the side.
@@ -193,8 +206,8 @@ __global__ __launch_bounds__(u8c::kWgThreads) void conv_u8_wgrad_kernel(const ui
                                                                         int K, float scale, int bias_rows) {
     using namespace u8c;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *ximg = smem;                                                    // [img_bytes] (+ slack to a multiple of 16)
-    uint4 *pimg = (uint4 *)(smem + ((g.img_bytes + 15) & ~15));              // [3][Gpad][32] fragments
+    uint8_t *ximg = smem;                                                    // [img_bytes] bf16 (+ slack to a multiple of 32 bytes)
+    uint4 *pimg = (uint4 *)(smem + 2 * ((g.img_bytes + 15) & ~15));          // [3][Gpad][32] fragments
     const int tid = threadIdx.x, lane = tid & 63, kh = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int co = tid & 31;
@@ -237,10 +250,24 @@ __global__ __launch_bounds__(u8c::kWgThreads) void conv_u8_wgrad_kernel(const ui
     int b = blockIdx.x;
     if (b < B) prefetch(b);
     for (; b < B; b += gridDim.x) {
-        // ---- phase A: this image's bytes and cut-up dY into LDS -------------------------------------------------
+        // ---- phase A: this image as bf16 (every byte converted once, not once per kernel row and tap that meets it) and
+        //      cut-up dY into LDS ------------------------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < kXR; i++)
-            if ((tid + i * kWgThreads) * 16 < g.img_bytes) ((uint4 *)ximg)[tid + i * kWgThreads] = xr[i];
+            if ((tid + i * kWgThreads) * 16 < g.img_bytes) {
+                const unsigned w[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+                unsigned o[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const unsigned src = w[q >> 1];
+                    const float f0 = (float)((src >> (16 * (q & 1))) & 0xffu);
+                    const float f1 = (float)((src >> (16 * (q & 1) + 8)) & 0xffu);
+                    o[q] = pack_hi16(__float_as_uint(f0), __float_as_uint(f1));
+                }
+                uint4 *dst = (uint4 *)ximg + 2 * (tid + i * kWgThreads);
+                dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            }
 #pragma unroll
         for (int i = 0; i < kNR; i++)
             if (dyoff[i] >= 0) {
@@ -263,23 +290,26 @@ __global__ __launch_bounds__(u8c::kWgThreads) void conv_u8_wgrad_kernel(const ui
         if (b + (int)gridDim.x < B) prefetch(b + gridDim.x);
 
         // ---- phase B: groups 2 kb + h, two per product step ---------------------------------------------------------
-        int ohp = 0, owq = h;              // group h of step 0 (Q >= 2)
-        auto fetch_bytes = [&](unsigned (&v)[8]) {
-            const uint8_t *p0 = ximg + (8 * ohp + kh) * g.row_bytes + 64 * owq + r;
-            const uint8_t *p1 = p0 + 4 * g.row_bytes;
-#pragma unroll
-            for (int dx = 0; dx < 4; dx++) {
-                v[dx] = p0[16 * dx];
-                v[4 + dx] = p1[16 * dx];
-            }
+        // lane (tap r, half h) takes the eight pixels of its group at this tap: element 2 q + e of the fragment is pixel
+        // (dy, dx) = (q >> 1, 2 (q & 1) + e) of the 2 x 4 block; 16-bit reads land in register halves as they are
+        const unsigned short *xp = (const unsigned short *)ximg + kh * g.row_bytes + 64 * h + r;      // group h of step 0 (Q >= 2)
+        int owq = h;
+        const int row4 = 4 * g.row_bytes, wrap = 8 * g.row_bytes - 64 * g.Q;
+        auto fetch_frag = [&](uint4 &f) {
+            const unsigned short *p1 = xp + row4;
+            f.x = (unsigned)xp[0] | ((unsigned)xp[16] << 16);
+            f.y = (unsigned)xp[32] | ((unsigned)xp[48] << 16);
+            f.z = (unsigned)p1[0] | ((unsigned)p1[16] << 16);
+            f.w = (unsigned)p1[32] | ((unsigned)p1[48] << 16);
         };
-        auto advance = [&]() {
+        auto advance = [&]() {          // two groups on: 128 taps-of-a-row further, or into the next pair of output rows
             owq += 2;
-            if (owq >= g.Q) { owq -= g.Q; ohp++; }
+            xp += 128;
+            if (owq >= g.Q) { owq -= g.Q; xp += wrap; }
         };
-        unsigned xb[2][8];
+        uint4 xf[2];
         uint4 wf[2][3];
-        fetch_bytes(xb[0]);
+        fetch_frag(xf[0]);
 #pragma unroll
         for (int p = 0; p < 3; p++) wf[0][p] = pimg[(p * g.Gpad + h) * 32 + r];
         const int nkb = g.Gpad >> 1;
@@ -289,16 +319,12 @@ __global__ __launch_bounds__(u8c::kWgThreads) void conv_u8_wgrad_kernel(const ui
                 if (kb + par < nkb) {
                     advance();
                     if (kb + par + 1 < nkb) {
-                        fetch_bytes(xb[par ^ 1]);
+                        fetch_frag(xf[par ^ 1]);
 #pragma unroll
                         for (int p = 0; p < 3; p++) wf[par ^ 1][p] = pimg[(p * g.Gpad + 2 * (kb + par + 1) + h) * 32 + r];
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    unsigned o[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        o[q] = pack_hi16(__float_as_uint((float)xb[par][2 * q]), __float_as_uint((float)xb[par][2 * q + 1]));
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, xf[par]);
 #pragma unroll
                     for (int p = 2; p >= 0; p--)
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, wf[par][p]), acc, 0, 0, 0);
@@ -333,7 +359,7 @@ static size_t conv_u8_wgrad_lds(const ConvShape &c) {
     const int G = c.OH * c.OW / 8, Gpad = (G + 1) & ~1;
     const size_t img = ((size_t)c.IH * c.IW * c.Cin + 15) & ~(size_t)15;
     // the padding group's byte reads may run a few image rows past the image: they land in the fragment area
-    return img + (size_t)3 * Gpad * 32 * 16;
+    return 2 * img + (size_t)3 * Gpad * 32 * 16;
 }
 
 bool conv_u8_wgrad_ok(const void *X, const float *dY, const ConvShape &c) {
@@ -349,7 +375,7 @@ bool conv_u8_wgrad_ok(const void *X, const float *dY, const ConvShape &c) {
 int conv_u8_wgrad_slabs(const void *X, const float *dY, const ConvShape &c, float *slabs, int max_slabs, int *nslabs,
                         hipStream_t s, bool bias_rows) {
     using namespace u8c;
-    int n = c.B < 256 ? c.B : 256;             // one workgroup (105 KB of LDS for 84 x 84 x 4) per CU
+    int n = c.B < 256 ? c.B : 256;             // one workgroup (133 KB of LDS for 84 x 84 x 4) per CU
     if (n > max_slabs) n = max_slabs;
     if (n < 1) n = 1;
     *nslabs = n;
