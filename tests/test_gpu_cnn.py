@@ -41,7 +41,11 @@ def _check(hip, spec, params, oracle, o_losses, theta, grads, losses, upstream=T
     assert max(float(np.abs(new[k] - o_params[k]).max()) for k in new) <= 2e-6
 
 
-@pytest.mark.parametrize("hwc,nact,T,E,B", [((36, 36, 2), 4, 4, 6, 20), ((44, 52, 4), 6, 3, 8, 24), ((84, 84, 4), 6, 2, 8, 16)])
+# (36, 36, 2): the first layer as a float32 product; (44, 52, 4), (84, 84, 4): its uint8 kernels (bf16 products of exact
+# pieces) — 24 frames end in a part-filled 128-pixel tile and an odd number of pixel groups per frame; 300 frames make the
+# workgroups of both kernels walk several tiles / frames each, unevenly
+@pytest.mark.parametrize("hwc,nact,T,E,B", [((36, 36, 2), 4, 4, 6, 20), ((44, 52, 4), 6, 3, 8, 24), ((84, 84, 4), 6, 2, 8, 16),
+                                            ((84, 84, 4), 6, 3, 100, 300)])
 def test_cnn_policy_grad(hip, hwc, nact, T, E, B):
     from baselines_amd import _lib
     spec = hip.PolicySpec(_lib.POLICY_CNN, _lib.DIST_CATEGORICAL, nact, 1, ob_hwc=hwc)
