@@ -18,7 +18,7 @@ for w in $WL; do
     echo "stats $w done"
 done
 for w in $WL; do
-    case $w in mujoco_*) ;; *) continue;; esac
+    case $w in mujoco_*|atari_cnn) ;; *) continue;; esac
     for c in FETCH_SIZE WRITE_SIZE; do
         rm -rf $OUT/${c}_$w
         timeout -s KILL 200 rocprofv3 --kernel-trace --pmc $c -d $OUT/${c}_$w -- python3 bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > $OUT/${c}_$w.log 2>&1 || { tail -5 $OUT/${c}_$w.log; exit 1; }
