@@ -355,10 +355,11 @@ static ConvGeom geom(const ConvShape &c) {
 }
 
 int conv_forward(const void *X, bool x_u8, const float *W, const float *b, float *Y, const ConvShape &c,
-                 hipStream_t s) {
+                 hipStream_t s, const int32_t *rows) {
     const int64_t M = (int64_t)c.B * c.OH * c.OW;
     const int K = c.KH * c.KW * c.Cin;
-    if (x_u8 && conv_u8_forward_ok(X, c)) return conv_u8_forward(X, W, b, Y, c, s);
+    if (x_u8 && conv_u8_forward_ok(X, c)) return conv_u8_forward(X, W, b, Y, c, s, rows);
+    if (rows) { set_error("conv_forward: a frame list needs the uint8 kernels"); return PPO2HIP_EINVAL; }
     RowMajor Bm{W, c.Cout};
     EpiBiasAct ep{Y, c.Cout, b, ACT_RELU, 0, x_u8 ? kU8Scale : 1.f};
     if (x_u8) return launch_gemm(Im2col<true>{X, geom(c)}, Bm, ep, M, c.Cout, K, 1, s, "conv_forward");
@@ -371,10 +372,11 @@ int conv_wgrad_max_slabs(const ConvShape &c) {
 }
 
 int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape &c, float *slabs, int max_slabs,
-                     int *nslabs, hipStream_t s, bool bias_rows) {
+                     int *nslabs, hipStream_t s, bool bias_rows, const int32_t *frame_rows) {
     const int64_t M = (int64_t)c.B * c.OH * c.OW;
     const int K = c.KH * c.KW * c.Cin;
-    if (x_u8 && conv_u8_wgrad_ok(X, dY, c)) return conv_u8_wgrad_slabs(X, dY, c, slabs, max_slabs, nslabs, s, bias_rows);
+    if (x_u8 && conv_u8_wgrad_ok(X, dY, c)) return conv_u8_wgrad_slabs(X, dY, c, slabs, max_slabs, nslabs, s, bias_rows, frame_rows);
+    if (frame_rows) { set_error("conv_wgrad: a frame list needs the uint8 kernels"); return PPO2HIP_EINVAL; }
     int n = conv_wgrad_max_slabs(c);
     if (n > max_slabs) n = max_slabs;
     *nslabs = n;

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(u8c::kThreads, 3) void conv_u8_forward_kernel(const
                                                                         const float *__restrict__ W,
                                                                         const float *__restrict__ bias,
                                                                         float *__restrict__ Y, u8c::Geom g, int64_t M,
-                                                                        int64_t ntiles, float scale) {
+                                                                        int64_t ntiles, float scale,
+                                                                        const int32_t *__restrict__ rows) {
     using namespace u8c;
     constexpr int DS = KH * CPR;                 // 32-tap runs = pairs of k-steps
     constexpr int K = DS * 32;
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(u8c::kThreads, 3) void conv_u8_forward_kernel(const
         const unsigned ohw = (unsigned)(g.OH * g.OW);
         const unsigned b = m / ohw, rem = m - b * ohw;
         const unsigned oh = rem / (unsigned)g.OW, ow = rem - oh * (unsigned)g.OW;
-        const uint8_t *p = X + (((int64_t)b * g.IH + oh * g.S) * g.IW + ow * g.S) * g.Cin + 16 * h;
+        const int64_t frame = rows ? rows[b] : b;            // frames read where they lie in the rollout
+        const uint8_t *p = X + ((frame * g.IH + oh * g.S) * g.IW + ow * g.S) * g.Cin + 16 * h;
 #pragma unroll
         for (int kh = 0; kh < KH; kh++)
 #pragma unroll
@@ -163,14 +165,15 @@ bool conv_u8_forward_ok(const void *X, const ConvShape &c) {
            (int64_t)c.B * c.OH * c.OW < 0x7fffffffll && (c.stride * c.Cin) % 16 == 0 && (c.IW * c.Cin) % 16 == 0 && ((int64_t)c.IH * c.IW * c.Cin) % 16 == 0 && c.B > 0;
 }
 
-int conv_u8_forward(const void *X, const float *W, const float *b, float *Y, const ConvShape &c, hipStream_t s) {
+int conv_u8_forward(const void *X, const float *W, const float *b, float *Y, const ConvShape &c, hipStream_t s,
+                    const int32_t *rows) {
     using namespace u8c;
     const int64_t M = (int64_t)c.B * c.OH * c.OW;
     const int64_t ntiles = ceil_div(M, 128);
     const int grid = (int)(ntiles < 768 ? ntiles : 768);       // three workgroups a CU (48 KB of LDS each), each walks its tiles
     Geom g{c.IH, c.IW, c.Cin, c.stride, c.OH, c.OW};
     hipLaunchKernelGGL((conv_u8_forward_kernel<8, 1>), dim3(grid), dim3(kThreads), 0, s, (const uint8_t *)X, W, b, Y, g, M,
-                       ntiles, 1.0f / 255.0f);
+                       ntiles, 1.0f / 255.0f, rows);
     return check_launch("conv_u8_forward");
 }
 
@@ -203,7 +206,8 @@ struct WGeom {
 __global__ __launch_bounds__(u8c::kWgThreads) void conv_u8_wgrad_kernel(const uint8_t *__restrict__ X,
                                                                         const float *__restrict__ dY,
                                                                         float *__restrict__ slabs, u8c::WGeom g, int B,
-                                                                        int K, float scale, int bias_rows) {
+                                                                        int K, float scale, int bias_rows,
+                                                                        const int32_t *__restrict__ rows) {
     using namespace u8c;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *ximg = smem;                                                    // [img_bytes] bf16 (+ slack to a multiple of 32 bytes)
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(u8c::kWgThreads) void conv_u8_wgrad_kernel(const ui
         dyoff[i] = grp < g.G ? ((2 * ohp) * g.OW + 4 * owq) * kCout + co : -1;
     }
     auto prefetch = [&](int b) {
-        const uint4 *src = (const uint4 *)(X + (int64_t)b * g.img_bytes);
+        const uint4 *src = (const uint4 *)(X + (int64_t)(rows ? rows[b] : b) * g.img_bytes);
 #pragma unroll
         for (int i = 0; i < kXR; i++)
             if ((tid + i * kWgThreads) * 16 < g.img_bytes) xr[i] = src[tid + i * kWgThreads];
@@ -372,8 +376,13 @@ bool conv_u8_wgrad_ok(const void *X, const float *dY, const ConvShape &c) {
            G <= 16 * u8c::kNR && conv_u8_wgrad_lds(c) <= 150 * 1024 && c.B > 0 && dY != nullptr;
 }
 
+bool conv_u8_direct_ok(const void *X, const ConvShape &c) {
+    static const bool gathered = getenv("PPO2HIP_CONV_U8_GATHER") != nullptr;
+    return !gathered && conv_u8_forward_ok(X, c) && conv_u8_wgrad_ok(X, (const float *)X, c);
+}
+
 int conv_u8_wgrad_slabs(const void *X, const float *dY, const ConvShape &c, float *slabs, int max_slabs, int *nslabs,
-                        hipStream_t s, bool bias_rows) {
+                        hipStream_t s, bool bias_rows, const int32_t *rows) {
     using namespace u8c;
     int n = c.B < 256 ? c.B : 256;             // one workgroup (133 KB of LDS for 84 x 84 x 4) per CU
     if (n > max_slabs) n = max_slabs;
@@ -391,7 +400,7 @@ int conv_u8_wgrad_slabs(const void *X, const float *dY, const ConvShape &c, floa
         return PPO2HIP_EINVAL;
     }
     hipLaunchKernelGGL(conv_u8_wgrad_kernel, dim3(n), dim3(kWgThreads), lds, s, (const uint8_t *)X, dY, slabs, g, c.B, K,
-                       1.0f / 255.0f, bias_rows ? 1 : 0);
+                       1.0f / 255.0f, bias_rows ? 1 : 0, rows);
     return check_launch("conv_u8_wgrad");
 }
 

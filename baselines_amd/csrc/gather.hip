@@ -62,6 +62,7 @@ struct SmallGather {
     float *o_returns, *o_values, *o_neglogpacs, *o_advs;
     uint8_t *o_masks;
     uint32_t *o_actions;
+    int32_t *o_rows;      // optional: the rollout row of every minibatch sample
 };
 
 __global__ void gather_small_kernel(SmallGather g, const int32_t *__restrict__ idx, int64_t B, int64_t limit, unsigned *fault) {
@@ -74,6 +75,7 @@ __global__ void gather_small_kernel(SmallGather g, const int32_t *__restrict__ i
         g.o_values[i * g.nvalue + k] = g.values[r * g.nvalue + k];
     }
     g.o_neglogpacs[i] = g.neglogpacs[r];
+    if (g.o_rows) g.o_rows[i] = (int32_t)r;
     double a = g.adv_f64 ? ((const double *)g.advs)[r] : (double)((const float *)g.advs)[r];
     if (g.stats) {
         // (a - mean) / (std + 1e-8), population std
@@ -104,7 +106,9 @@ int gather_minibatch(const GatherArgs &g, hipStream_t s) {
     unsigned *fault = fault_word();
     if (!fault) return PPO2HIP_EINVAL;
     const int64_t limit = rollout_samples(*ro);
-    // observations
+    int rc = 0;
+    // observations (unless the consumer reads them where they lie)
+    if (!g.obs_rows) {
     const bool a16 = (g.ob_bytes % 16 == 0) && ((uintptr_t)ro->obs % 16 == 0) && ((uintptr_t)g.obs % 16 == 0) && g.ob_bytes >= 1024;
     if (a16) {
         hipLaunchKernelGGL(gather_rows16_kernel, dim3((unsigned)B), dim3(256), 0, s, (const uint4 *)ro->obs, g.idx, B,
@@ -120,14 +124,16 @@ int gather_minibatch(const GatherArgs &g, hipStream_t s) {
         hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3((unsigned)nb), dim3(256), 0, s, (const uint8_t *)ro->obs,
                            g.idx, B, g.ob_bytes, ro->T, ro->E, (uint8_t *)g.obs, limit, fault);
     }
-    int rc = check_launch("gather_rows");
+    rc = check_launch("gather_rows");
     if (rc) return rc;
+    }
     SmallGather sg;
     sg.returns = ro->returns; sg.values = ro->values; sg.neglogpacs = ro->neglogpacs; sg.advs = ro->advs;
     sg.masks = ro->masks; sg.actions = ro->actions; sg.adv_f64 = ro->adv_f64; sg.T = ro->T; sg.E = ro->E;
     sg.nvalue = g.nvalue; sg.ac_words = (int)(g.ac_bytes / 4); sg.stats = g.stats;
     sg.o_returns = g.returns; sg.o_values = g.values; sg.o_neglogpacs = g.neglogpacs; sg.o_advs = g.advs;
     sg.o_masks = (g.masks && ro->masks) ? g.masks : nullptr; sg.o_actions = (uint32_t *)g.actions;
+    sg.o_rows = g.obs_rows;
     hipLaunchKernelGGL(gather_small_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, s, sg, g.idx, B, limit, fault);
     return check_launch("gather_small");
 }

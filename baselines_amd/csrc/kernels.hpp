@@ -44,17 +44,22 @@ struct ConvShape {
     int B, IH, IW, Cin, KH, KW, stride, OH, OW, Cout;
 };
 // Y[B,OH,OW,Cout] = relu(conv(X) + b); X float32 NHWC, or uint8 NHWC scaled by 1/255 (x_u8)
+//   rows (uint8 only, optional): frame i of the batch is frame rows[i] of X — only where conv_u8_direct_ok(c) holds
 int conv_forward(const void *X, bool x_u8, const float *W, const float *b, float *Y, const ConvShape &c,
-                 hipStream_t s);
+                 hipStream_t s, const int32_t *rows = nullptr);
 // the uint8 layer on the bf16 matrix pipe with float32-exact products (8 x 8 kernels of 32-byte rows, 32 channels)
 bool conv_u8_forward_ok(const void *X, const ConvShape &c);
-int conv_u8_forward(const void *X, const float *W, const float *b, float *Y, const ConvShape &c, hipStream_t s);
+int conv_u8_forward(const void *X, const float *W, const float *b, float *Y, const ConvShape &c, hipStream_t s,
+                    const int32_t *rows);
 bool conv_u8_wgrad_ok(const void *X, const float *dY, const ConvShape &c);
 int conv_u8_wgrad_slabs(const void *X, const float *dY, const ConvShape &c, float *slabs, int max_slabs, int *nslabs,
-                        hipStream_t s, bool bias_rows);
+                        hipStream_t s, bool bias_rows, const int32_t *rows);
+// both uint8 kernels take this layer: its frames can then be read where they lie (a list of frame numbers instead of a
+// gathered copy)
+bool conv_u8_direct_ok(const void *X, const ConvShape &c);
 // slabs[z][(KH*KW*Cin+1), Cout] as fc_wgrad_slabs
 int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape &c, float *slabs,
-                     int max_slabs, int *nslabs, hipStream_t s, bool bias_rows = true);
+                     int max_slabs, int *nslabs, hipStream_t s, bool bias_rows = true, const int32_t *rows = nullptr);
 int conv_wgrad_max_slabs(const ConvShape &c);
 // dX[B,IH,IW,Cin] = conv_transpose(dY, W) * relu'(Xact)   (Xact = the layer's float32 input activation)
 //   colsum_rows (optional): on return *nrows rows of Cin column sums of dX (one per row tile and parity class), or
@@ -82,6 +87,7 @@ struct GatherArgs {
     void *actions;
     float *returns, *values, *neglogpacs, *advs;
     uint8_t *masks;      // may be null
+    int32_t *obs_rows = nullptr;   // when set: the observation rows are NOT copied; row numbers (into ro->obs) are left here instead
 };
 int gather_minibatch(const GatherArgs &g, hipStream_t s);
 int gather_states(const float *states, const int32_t *envs, int nenv_mb, int width, float *out, hipStream_t s);

@@ -396,10 +396,10 @@ static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver 
 
 // conv trunk + fc1: X (uint8 NHWC) -> F [B, 512]
 static int cnn_trunk_forward(const ppo2hip_policy_desc &d, const Layout &L, const float *p, const void *X,
-                             const CnnBuf &w, int64_t B, hipStream_t s) {
+                             const CnnBuf &w, int64_t B, hipStream_t s, const int32_t *rows = nullptr) {
     const CnnDims k = cnn_dims(d);
     int rc;
-    if ((rc = conv_forward(X, true, p + L.off("c1/w"), p + L.off("c1/b"), w.Y1, conv_shape((int)B, k.H, k.W, k.C, 8, 4, 32), s))) return rc;
+    if ((rc = conv_forward(X, true, p + L.off("c1/w"), p + L.off("c1/b"), w.Y1, conv_shape((int)B, k.H, k.W, k.C, 8, 4, 32), s, rows))) return rc;
     if ((rc = conv_forward(w.Y1, false, p + L.off("c2/w"), p + L.off("c2/b"), w.Y2, conv_shape((int)B, k.h1, k.w1, 32, 4, 2, 64), s))) return rc;
     if ((rc = conv_forward(w.Y2, false, p + L.off("c3/w"), p + L.off("c3/b"), w.Y3, conv_shape((int)B, k.h2, k.w2, 64, 3, 1, 64), s))) return rc;
     return fc_forward(w.Y3, k.flat, p + L.off("fc1/w"), p + L.off("fc1/b"), w.F, 512, (int)B, 512, k.flat, ACT_RELU, false, s);
@@ -468,11 +468,12 @@ static int wgrad_into(const float *X, int ldx, const float *dY, int lddy, int64_
 // bias_rows: `nbias` rows of Cout column sums of dY that the product which wrote dY left behind (its row tiles), or
 // null — then the bias gradient costs a pass of its own over dY
 static int conv_wgrad_into(const void *X, bool u8, const float *dY, const ConvShape &c, float *slabs, int max_slabs,
-                           float *dst, hipStream_t s, const float *bias_rows = nullptr, int nbias = 0) {
+                           float *dst, hipStream_t s, const float *bias_rows = nullptr, int nbias = 0,
+                           const int32_t *rows = nullptr) {
     int ns = 0;
     const int64_t K = (int64_t)c.KH * c.KW * c.Cin;
     const bool given = bias_rows && nbias > 0 && wgrad_bias_separately((int)K);
-    int rc = conv_wgrad_slabs(X, u8, dY, c, slabs, max_slabs, &ns, s, !given);
+    int rc = conv_wgrad_slabs(X, u8, dY, c, slabs, max_slabs, &ns, s, !given, rows);
     if (rc) return rc;
     if (!given) return reduce_slabs(slabs, ns, (K + 1) * c.Cout, dst, false, s);
     if ((rc = reduce_slabs(slabs, ns, K * c.Cout, dst, false, s, (K + 1) * c.Cout))) return rc;
@@ -502,9 +503,19 @@ static int cnn_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
     g.ro = &ro; g.idx = idx; g.B = B; g.ob_bytes = (int64_t)k.H * k.W * k.C; g.ac_bytes = 4; g.nvalue = 1; g.stats = stats;
     g.obs = w.X; g.actions = w.ACT; g.returns = w.RET; g.values = w.OLDV; g.neglogpacs = w.NLP; g.advs = w.ADV;
     g.masks = k.lstm ? w.MASK : nullptr;
+    // Frames the uint8 kernels of conv1 can take are read where they lie in the rollout (a 231 MB copy per 8192-frame
+    // minibatch saved): the gather then leaves the frames' row numbers at the head of the frame buffer instead.
+    const bool direct = conv_u8_direct_ok(ro.obs, conv_shape((int)B, k.H, k.W, k.C, 8, 4, 32)) && ro.n < 0x7fffffffll;
+    const int32_t *rows = nullptr;
+    const void *frames = w.X;
+    if (direct) {
+        g.obs_rows = (int32_t *)w.X;
+        rows = g.obs_rows;
+        frames = ro.obs;
+    }
     int rc;
     if ((rc = gather_minibatch(g, s))) return rc;
-    if ((rc = cnn_trunk_forward(d, L, p, w.X, w, B, s))) return rc;
+    if ((rc = cnn_trunk_forward(d, L, p, frames, w, B, s, rows))) return rc;
     const float *feat = w.F;
     if (k.lstm) {
         if ((rc = gather_states(ro.states, mb_envs, nenv, 2 * k.nh, w.S0, s))) return rc;
@@ -598,7 +609,7 @@ static int cnn_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
     if ((rc = conv_wgrad_into(w.Y1, false, w.dY2, c2, w.slabs, w.max_slabs, grads + L.off("c2/w"), s, hand_on ? w.CS : nullptr, nb))) return rc;
     nb = 0;
     if ((rc = conv_dgrad(w.dY2, p + L.off("c2/w"), w.Y1, w.dY1, c2, s, hand_on ? w.CS : nullptr, &nb))) return rc;
-    if ((rc = conv_wgrad_into(w.X, true, w.dY1, c1, w.slabs, w.max_slabs, grads + L.off("c1/w"), s, hand_on ? w.CS : nullptr, nb))) return rc;
+    if ((rc = conv_wgrad_into(frames, true, w.dY1, c1, w.slabs, w.max_slabs, grads + L.off("c1/w"), s, hand_on ? w.CS : nullptr, nb, rows))) return rc;
     return 0;
 }
 
