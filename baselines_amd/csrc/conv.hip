@@ -327,6 +327,7 @@ struct DgradWPM {   // B(k', n = ci) = W[ph + S (kh0 + kh'), pw + S (kw0 + kw'),
 };
 struct EpiActGradPM {   // row m of the pixel-major order -> pixel (b, S ih' + ph, S iw' + pw) of dX, times relu'(X)
     static constexpr bool kColSum = true;
+    static constexpr bool kColCtx = true;
     typedef int64_t Row;
     float *dX;
     const float *Xact;
@@ -338,12 +339,14 @@ struct EpiActGradPM {   // row m of the pixel-major order -> pixel (b, S ih' + p
         q.decode(m, b, ih, iw);
         return ((b * q.g.IH + q.g.S * ih + q.ph) * q.g.IW + q.g.S * iw + q.pw) * q.g.Cin;
     }
-    __device__ float operator()(const Row &r, int n, float v) const {
-        int64_t o = r + n;
-        if (q.merged) {          // column n = ((ph, pw), ci): the pixel of its class
-            const int cls = n / q.g.Cin, ci = n - cls * q.g.Cin, ph = cls / q.g.S, pw = cls - ph * q.g.S;
-            o = r + (int64_t)(ph * q.g.IW + pw) * q.g.Cin + ci;
-        }
+    // column n of the merged product = ((ph, pw), ci): the pixel of its class
+    __device__ int64_t col(int n) const {
+        if (!q.merged) return n;
+        const int cls = n / q.g.Cin, ci = n - cls * q.g.Cin, ph = cls / q.g.S, pw = cls - ph * q.g.S;
+        return (int64_t)(ph * q.g.IW + pw) * q.g.Cin + ci;
+    }
+    __device__ float operator()(const Row &r, int64_t cc, float v) const {
+        const int64_t o = r + cc;
         v = Xact[o] > 0.f ? v : 0.f;
         dX[o] = v;
         return v;

@@ -54,6 +54,14 @@ struct col_sum : std::false_type {};
 template <class E>
 struct col_sum<E, std::enable_if_t<E::kColSum>> : std::true_type {};
 
+// an epilogue with `static constexpr bool kColCtx = true` has `int64_t col(int n) const` — what an output element's
+// address owes to its column, worked out once per thread and 32-column block instead of once per element — and takes
+// that value where the others take n
+template <class E, class = void>
+struct col_ctx : std::false_type {};
+template <class E>
+struct col_ctx<E, std::enable_if_t<E::kColCtx>> : std::true_type {};
+
 // LDS row pitch: rows lh = 0 / 1 of an operand read must land on different bank halves (pitch = 32 mod 64)
 // when rows are written as vectors; the scalar path keeps the odd pitch that spreads its k-fast writes.
 // Vectors along k written with the k group as the fastest lane index (four lanes cover 64 contiguous bytes of one
@@ -372,6 +380,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     for (int nb = 0; nb < NB; nb++) {
         const int n = n0 + (wn * NB + nb) * 32 + li;
         csum[nb] = 0.f;
+        if constexpr (col_ctx<EP>::value) {
+            static_assert(col_sum<EP>::value, "column contexts come with column sums");
+            const int64_t cc = ep.col(n < N ? n : 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m0 + ml < M && n < N) csum[nb] += ep(rows[ml], cc, acc[nb][r]);
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -379,6 +396,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
                 if constexpr (col_sum<EP>::value) csum[nb] += ep(rows[ml], n, acc[nb][r]);
                 else ep(rows[ml], n, acc[nb][r]);
             }
+        }
         }
     }
     // The consumer of a gradient tensor wants its column sums too (the bias gradient of the layer it came out of):
