@@ -333,6 +333,7 @@ struct EpiActGradPM {   // row m of the pixel-major order -> pixel (b, S ih' + p
     const float *Xact;
     PixelMajor q;
     float *colsum;           // [row tiles][N] column sums of the stored values, or null
+    const uint32_t *bits;    // packed (Xact > 0), read in place of Xact when set
     __device__ Row row(int64_t m, int) const {
         int64_t b;
         int ih, iw;
@@ -347,7 +348,8 @@ struct EpiActGradPM {   // row m of the pixel-major order -> pixel (b, S ih' + p
     }
     __device__ float operator()(const Row &r, int64_t cc, float v) const {
         const int64_t o = r + cc;
-        v = Xact[o] > 0.f ? v : 0.f;
+        const bool on = bits ? ((bits[o >> 5] >> (o & 31)) & 1u) != 0u : Xact[o] > 0.f;
+        v = on ? v : 0.f;
         dX[o] = v;
         return v;
     }
@@ -358,11 +360,11 @@ static ConvGeom geom(const ConvShape &c) {
 }
 
 int conv_forward(const void *X, bool x_u8, const float *W, const float *b, float *Y, const ConvShape &c,
-                 hipStream_t s, const int32_t *rows) {
+                 hipStream_t s, const int32_t *rows, uint32_t *relu_bits) {
     const int64_t M = (int64_t)c.B * c.OH * c.OW;
     const int K = c.KH * c.KW * c.Cin;
-    if (x_u8 && conv_u8_forward_ok(X, c)) return conv_u8_forward(X, W, b, Y, c, s, rows);
-    if (rows) { set_error("conv_forward: a frame list needs the uint8 kernels"); return PPO2HIP_EINVAL; }
+    if (x_u8 && conv_u8_forward_ok(X, c)) return conv_u8_forward(X, W, b, Y, c, s, rows, relu_bits);
+    if (rows || relu_bits) { set_error("conv_forward: a frame list or rectifier bits need the uint8 kernels"); return PPO2HIP_EINVAL; }
     RowMajor Bm{W, c.Cout};
     EpiBiasAct ep{Y, c.Cout, b, ACT_RELU, 0, x_u8 ? kU8Scale : 1.f};
     if (x_u8) return launch_gemm(Im2col<true>{X, geom(c)}, Bm, ep, M, c.Cout, K, 1, s, "conv_forward");
@@ -482,8 +484,9 @@ int64_t conv_dgrad_colsum_rows(const ConvShape &c) {
 }
 
 int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, const ConvShape &c, hipStream_t s,
-               float *colsum_rows, int *nrows) {
+               float *colsum_rows, int *nrows, const uint32_t *relu_bits) {
     if (nrows) *nrows = 0;
+    if (c.Cin != 32) relu_bits = nullptr;       // one word per pixel: the packed bits line up with the tensor for 32 channels only
     if (c.stride > 1 && c.KH % c.stride == 0 && c.KW % c.stride == 0) {
         const int S = c.stride, KHp = c.KH / S, KWp = c.KW / S;
         if (c.IH % S == 0 && c.IW % S == 0 && pixel_major_ok(c, (int64_t)c.B * (c.IH / S) * (c.IW / S)) && KHp <= c.IH / S &&
@@ -493,7 +496,7 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
             const PixelMajor q{geom(c), 0, 0, IHp, IWp, KHp, KWp, 1, 0, 0, 0};
             const int64_t Mq = (int64_t)c.B * IHp * IWp;
             if (nrows && colsum_rows) *nrows = (int)(gemm_row_tiles(Mq, S * S * c.Cin, 1) * S * S);      // [tile][class][ci]
-            return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, colsum_rows}, Mq, S * S * c.Cin,
+            return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, colsum_rows, relu_bits}, Mq, S * S * c.Cin,
                                KHp * KWp * c.Cout, 1, s, "conv_dgrad");
         }
         for (int ph = 0; ph < S; ph++)
@@ -504,7 +507,7 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
                 const int K = KHp * KWp * c.Cout;
                 if (pixel_major_ok(c, M) && KHp <= IHp && KWp <= IWp) {
                     const PixelMajor q{geom(c), ph, pw, IHp, IWp, KHp, KWp, 0, 0, 0, 0};
-                    int rc = launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, nullptr}, M, c.Cin, K, 1, s, "conv_dgrad");
+                    int rc = launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, nullptr, relu_bits}, M, c.Cin, K, 1, s, "conv_dgrad");
                     if (rc) return rc;
                     continue;
                 }
@@ -519,7 +522,7 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
     if (c.stride == 1 && pixel_major_ok(c, M) && c.KH <= c.IH && c.KW <= c.IW) {
         const PixelMajor q{geom(c), 0, 0, c.IH, c.IW, c.KH, c.KW, 0, 0, 0, 0};
         if (nrows && colsum_rows) *nrows = (int)gemm_row_tiles(M, c.Cin, 1);
-        return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, colsum_rows}, M, c.Cin, K, 1, s, "conv_dgrad");
+        return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, colsum_rows, relu_bits}, M, c.Cin, K, 1, s, "conv_dgrad");
     }
     EpiActGrad ep{dX, c.Cin, Xact, c.Cin, ACT_RELU, 0, nullptr};
     return launch_gemm(DgradCol{dY, geom(c)}, DgradW{W, geom(c)}, ep, M, c.Cin, K, 1, s, "conv_dgrad");

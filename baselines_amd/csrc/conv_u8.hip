@@ -42,7 +42,8 @@ __global__ __launch_bounds__(u8c::kThreads, 3) void conv_u8_forward_kernel(const
                                                                         const float *__restrict__ bias,
                                                                         float *__restrict__ Y, u8c::Geom g, int64_t M,
                                                                         int64_t ntiles, float scale,
-                                                                        const int32_t *__restrict__ rows) {
+                                                                        const int32_t *__restrict__ rows,
+                                                                        uint32_t *__restrict__ relu_bits) {
     using namespace u8c;
     constexpr int DS = KH * CPR;                 // 32-tap runs = pairs of k-steps
     constexpr int K = DS * 32;
@@ -140,13 +141,28 @@ __global__ __launch_bounds__(u8c::kThreads, 3) void conv_u8_forward_kernel(const
         // ---- epilogue: rows (e & 3) + 8 (e >> 2) + 4 h of the wave's 32 pixels, column r = output channel --------
         const int64_t m0 = tile * 128 + wave * 32;
         float *y = Y + (m0 + 4 * h) * kCout + r;
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) v[e] = fmaxf(fmaf(acc[e], scale, bco), 0.f);
         if (m0 + 32 <= M) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) y[((e & 3) + 8 * (e >> 2)) * kCout] = fmaxf(fmaf(acc[e], scale, bco), 0.f);
+            for (int e = 0; e < 16; e++) y[((e & 3) + 8 * (e >> 2)) * kCout] = v[e];
         } else {
 #pragma unroll
             for (int e = 0; e < 16; e++)
-                if (m0 + (e & 3) + 8 * (e >> 2) + 4 * h < M) y[((e & 3) + 8 * (e >> 2)) * kCout] = fmaxf(fmaf(acc[e], scale, bco), 0.f);
+                if (m0 + (e & 3) + 8 * (e >> 2) + 4 * h < M) y[((e & 3) + 8 * (e >> 2)) * kCout] = v[e];
+        }
+        if (relu_bits) {
+            // which outputs the rectifier let through, one word per pixel (bit = channel = lane r): lane L < 32 collects
+            // the word of the wave's pixel L — register (L & 3) + 4 (L >> 3), lane half (L >> 2) & 1
+            unsigned mine = 0u;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const unsigned long long bal = __ballot(v[e] > 0.f);
+                const unsigned word = ((r >> 2) & 1) ? (unsigned)(bal >> 32) : (unsigned)bal;
+                mine = ((r & 3) + 4 * (r >> 3) == e) ? word : mine;
+            }
+            if (h == 0 && m0 + r < M) relu_bits[m0 + r] = mine;
         }
     };
     while (tile < ntiles) {
@@ -166,14 +182,14 @@ bool conv_u8_forward_ok(const void *X, const ConvShape &c) {
 }
 
 int conv_u8_forward(const void *X, const float *W, const float *b, float *Y, const ConvShape &c, hipStream_t s,
-                    const int32_t *rows) {
+                    const int32_t *rows, uint32_t *relu_bits) {
     using namespace u8c;
     const int64_t M = (int64_t)c.B * c.OH * c.OW;
     const int64_t ntiles = ceil_div(M, 128);
     const int grid = (int)(ntiles < 768 ? ntiles : 768);       // three workgroups a CU (48 KB of LDS each), each walks its tiles
     Geom g{c.IH, c.IW, c.Cin, c.stride, c.OH, c.OW};
     hipLaunchKernelGGL((conv_u8_forward_kernel<8, 1>), dim3(grid), dim3(kThreads), 0, s, (const uint8_t *)X, W, b, Y, g, M,
-                       ntiles, 1.0f / 255.0f, rows);
+                       ntiles, 1.0f / 255.0f, rows, relu_bits);
     return check_launch("conv_u8_forward");
 }
 

@@ -45,12 +45,13 @@ struct ConvShape {
 };
 // Y[B,OH,OW,Cout] = relu(conv(X) + b); X float32 NHWC, or uint8 NHWC scaled by 1/255 (x_u8)
 //   rows (uint8 only, optional): frame i of the batch is frame rows[i] of X — only where conv_u8_direct_ok(c) holds
+//   relu_bits (optional, same condition): one word per output pixel, bit co = (Y[pixel][co] > 0)
 int conv_forward(const void *X, bool x_u8, const float *W, const float *b, float *Y, const ConvShape &c,
-                 hipStream_t s, const int32_t *rows = nullptr);
+                 hipStream_t s, const int32_t *rows = nullptr, uint32_t *relu_bits = nullptr);
 // the uint8 layer on the bf16 matrix pipe with float32-exact products (8 x 8 kernels of 32-byte rows, 32 channels)
 bool conv_u8_forward_ok(const void *X, const ConvShape &c);
 int conv_u8_forward(const void *X, const float *W, const float *b, float *Y, const ConvShape &c, hipStream_t s,
-                    const int32_t *rows);
+                    const int32_t *rows, uint32_t *relu_bits);
 bool conv_u8_wgrad_ok(const void *X, const float *dY, const ConvShape &c);
 int conv_u8_wgrad_slabs(const void *X, const float *dY, const ConvShape &c, float *slabs, int max_slabs, int *nslabs,
                         hipStream_t s, bool bias_rows, const int32_t *rows);
@@ -62,10 +63,11 @@ int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape 
                      int max_slabs, int *nslabs, hipStream_t s, bool bias_rows = true, const int32_t *rows = nullptr);
 int conv_wgrad_max_slabs(const ConvShape &c);
 // dX[B,IH,IW,Cin] = conv_transpose(dY, W) * relu'(Xact)   (Xact = the layer's float32 input activation)
+//   relu_bits (optional, Cin = 32): bit i of the array = (Xact[i] > 0), read in place of Xact — 1/32 of the bytes
 //   colsum_rows (optional): on return *nrows rows of Cin column sums of dX (one per row tile and parity class), or
 //   *nrows = 0 when the route taken does not produce them; max_rows = conv_dgrad_colsum_rows(c)
 int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, const ConvShape &c, hipStream_t s,
-               float *colsum_rows = nullptr, int *nrows = nullptr);
+               float *colsum_rows = nullptr, int *nrows = nullptr, const uint32_t *relu_bits = nullptr);
 int64_t conv_dgrad_colsum_rows(const ConvShape &c);
 
 // ---- gather (gather.hip) ---------------------------------------------------------------

@@ -329,6 +329,7 @@ struct CnnBuf {
     int max_slabs;
     double *loss_partial;
     float *CS;                                 // per-tile column sums handed from an input-gradient product to the bias gradient
+    uint32_t *RB1;                             // rectifier bits of conv1's output, one word per pixel
 };
 
 static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver &c, CnnBuf &w, bool grad) {
@@ -359,6 +360,7 @@ static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver 
     w.dY3 = c.take<float>(B * k.flat);
     w.dY2 = c.take<float>(B * k.h2 * k.w2 * 64);
     w.dY1 = c.take<float>(B * k.h1 * k.w1 * 32);
+    w.RB1 = c.take<uint32_t>(B * k.h1 * k.w1);
     if (k.lstm) {
         w.DH = c.take<float>(B * k.nh);
         w.dhm = c.take<float>((int64_t)kLstmBwdParts * nenv * k.nh); w.dcm = c.take<float>((int64_t)nenv * k.nh);
@@ -396,10 +398,11 @@ static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver 
 
 // conv trunk + fc1: X (uint8 NHWC) -> F [B, 512]
 static int cnn_trunk_forward(const ppo2hip_policy_desc &d, const Layout &L, const float *p, const void *X,
-                             const CnnBuf &w, int64_t B, hipStream_t s, const int32_t *rows = nullptr) {
+                             const CnnBuf &w, int64_t B, hipStream_t s, const int32_t *rows = nullptr,
+                             uint32_t *relu_bits1 = nullptr) {
     const CnnDims k = cnn_dims(d);
     int rc;
-    if ((rc = conv_forward(X, true, p + L.off("c1/w"), p + L.off("c1/b"), w.Y1, conv_shape((int)B, k.H, k.W, k.C, 8, 4, 32), s, rows))) return rc;
+    if ((rc = conv_forward(X, true, p + L.off("c1/w"), p + L.off("c1/b"), w.Y1, conv_shape((int)B, k.H, k.W, k.C, 8, 4, 32), s, rows, relu_bits1))) return rc;
     if ((rc = conv_forward(w.Y1, false, p + L.off("c2/w"), p + L.off("c2/b"), w.Y2, conv_shape((int)B, k.h1, k.w1, 32, 4, 2, 64), s))) return rc;
     if ((rc = conv_forward(w.Y2, false, p + L.off("c3/w"), p + L.off("c3/b"), w.Y3, conv_shape((int)B, k.h2, k.w2, 64, 3, 1, 64), s))) return rc;
     return fc_forward(w.Y3, k.flat, p + L.off("fc1/w"), p + L.off("fc1/b"), w.F, 512, (int)B, 512, k.flat, ACT_RELU, false, s);
@@ -513,9 +516,12 @@ static int cnn_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
         rows = g.obs_rows;
         frames = ro.obs;
     }
+    // ... and conv1's forward kernel leaves one word of "output > 0" bits per pixel, which the product that writes dY1 reads
+    // for the rectifier's derivative in place of the 420 MB activation tensor (PPO2HIP_RELU_FROM_ACT=1 reads the tensor).
+    const bool defer_relu1 = direct && !getenv("PPO2HIP_RELU_FROM_ACT");
     int rc;
     if ((rc = gather_minibatch(g, s))) return rc;
-    if ((rc = cnn_trunk_forward(d, L, p, frames, w, B, s, rows))) return rc;
+    if ((rc = cnn_trunk_forward(d, L, p, frames, w, B, s, rows, defer_relu1 ? w.RB1 : nullptr))) return rc;
     const float *feat = w.F;
     if (k.lstm) {
         if ((rc = gather_states(ro.states, mb_envs, nenv, 2 * k.nh, w.S0, s))) return rc;
@@ -608,7 +614,7 @@ static int cnn_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
     if ((rc = conv_dgrad(w.dY3, p + L.off("c3/w"), w.Y2, w.dY2, c3, s, hand_on ? w.CS : nullptr, &nb))) return rc;
     if ((rc = conv_wgrad_into(w.Y1, false, w.dY2, c2, w.slabs, w.max_slabs, grads + L.off("c2/w"), s, hand_on ? w.CS : nullptr, nb))) return rc;
     nb = 0;
-    if ((rc = conv_dgrad(w.dY2, p + L.off("c2/w"), w.Y1, w.dY1, c2, s, hand_on ? w.CS : nullptr, &nb))) return rc;
+    if ((rc = conv_dgrad(w.dY2, p + L.off("c2/w"), w.Y1, w.dY1, c2, s, hand_on ? w.CS : nullptr, &nb, defer_relu1 ? w.RB1 : nullptr))) return rc;
     if ((rc = conv_wgrad_into(frames, true, w.dY1, c1, w.slabs, w.max_slabs, grads + L.off("c1/w"), s, hand_on ? w.CS : nullptr, nb, rows))) return rc;
     return 0;
 }
