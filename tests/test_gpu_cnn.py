@@ -136,3 +136,54 @@ def test_lnlstm_width_limit_is_an_error_not_a_fallback(hip):
     with pytest.raises(_lib.Ppo2HipError):
         hip.policy_forward(spec, torch.zeros(spec.nparams, device="cuda"), torch.zeros((2, 36, 36, 2), dtype=torch.uint8, device="cuda"),
                            fws, masks=torch.zeros(2, dtype=torch.uint8, device="cuda"), states=torch.zeros((2, 2200), device="cuda"))
+
+
+_ROUTE_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from baselines_amd import hip, _lib
+hwc, nact, T, E, B = (84, 84, 4), 6, 2, 80, 160
+spec = hip.PolicySpec(_lib.POLICY_CNN, _lib.DIST_CATEGORICAL, nact, 1, ob_hwc=hwc)
+g = torch.Generator(device="cuda"); g.manual_seed(11)
+theta = (torch.randn(spec.nparams, device="cuda", generator=g) * 0.03)
+obs = torch.randint(0, 256, (T, E) + hwc, device="cuda", generator=g, dtype=torch.uint8)
+f = lambda *s: torch.randn(*s, device="cuda", generator=g)
+acts = torch.randint(0, nact, (T, E), device="cuda", generator=g, dtype=torch.int32)
+rets, vals, nlp, advs = f(T, E, 1), f(T, E, 1), f(T, E).abs() + 1.0, f(T, E)
+rref = hip.RolloutRef(spec, obs, acts, rets, vals, nlp, advs, T, E)
+idx = torch.randperm(T * E, device="cuda", generator=g)[:B].to(torch.int32)
+stats = hip.adv_stats(rref.keep[5], idx, B, 1, T, E)
+grads = torch.zeros(spec.nparams, device="cuda"); losses = torch.zeros(8, device="cuda")
+ws = torch.empty(spec.grad_workspace_bytes(B), dtype=torch.uint8, device="cuda")
+hip.ppo_grad(spec, _lib.LossDesc(0.01, 0.5, 0.5, 1), theta, rref, idx, B, stats, 0.1, 1.0 / B, grads, losses, ws)
+torch.cuda.synchronize()
+np.savez(sys.argv[2], grads=grads.cpu().numpy(), losses=losses.cpu().numpy())
+"""
+
+
+def test_uint8_conv_kernels_agree_with_the_float32_route(tmp_path):
+    """conv1 on uint8 frames: the bf16-piece kernels (frames read in place, rectifier bits) against the float32 product on a
+    gathered copy, same inputs, two fresh processes (the switch is read once per process).  Every product term is exact in
+    both, so the routes differ by the rounding of running sums only: 2e-6 of each variable's largest gradient."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "route.py"
+    script.write_text(_ROUTE_SCRIPT)
+    out = {}
+    for name, env in (("pieces", {}), ("plain", {"PPO2HIP_CONV_U8_PLAIN": "1"})):
+        e = dict(os.environ)
+        e.update(env)
+        path = str(tmp_path / (name + ".npz"))
+        subprocess.run([sys.executable, str(script), root, path], check=True, env=e, timeout=240)
+        out[name] = np.load(path)
+    from baselines_amd import hip as h, _lib
+    spec = h.PolicySpec(_lib.POLICY_CNN, _lib.DIST_CATEGORICAL, 6, 1, ob_hwc=(84, 84, 4))
+    a, b = out["pieces"]["grads"], out["plain"]["grads"]
+    assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
+    for name, off, shp in spec.vars:
+        n = int(np.prod(shp))
+        ref = b[off:off + n]
+        assert np.abs(a[off:off + n] - ref).max() <= 2e-6 * max(np.abs(ref).max(), 1e-6), name
+    np.testing.assert_allclose(out["pieces"]["losses"][:5], out["plain"]["losses"][:5], rtol=2e-6, atol=1e-7)
