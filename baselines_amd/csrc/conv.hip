@@ -268,6 +268,7 @@ struct PixelMajor {
     }
 };
 struct DgradColPM {   // A(m, k')
+    bool full_slabs() const { return q.g.Cout % GEMM_BK == 0; }      // a tile's k range is whole taps of Cout terms
     static constexpr bool kInnerFast = true;
     static constexpr bool kTileK = true;
     typedef PixelRow Row;

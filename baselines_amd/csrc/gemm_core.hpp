@@ -12,7 +12,9 @@
 // the current one feeds the matrix cores.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "common.hpp"
 
@@ -74,7 +76,10 @@ __host__ __device__ constexpr int lds_pitch(int width, int mode) {
 // WM = number of wave rows, NB = 32-column blocks per wave:
 //   <4, 2>: 128 x 64, each wave 32 x 64;  <2, 1>: 64 x 64, each wave 32 x 32;  <4, 1>: 128 x 32, each wave 32 x 32
 // AV / BV = vector width of the A / B loads (1 = element-wise)
-template <class AL, class BL, class EP, int WM, int NB, int AV, int BV>
+// FULLK: every slab of every tile is a whole 16 steps of k (K, the split length and a tile-dependent k range are all
+// multiples of 16), so the loads need neither tests nor zero-fill — with float32 matrix products every vector instruction
+// saved in the main loop is matrix time won.
+template <class AL, class BL, class EP, int WM, int NB, int AV, int BV, bool FULLK = false>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, int64_t M, int N, int64_t K,
                                                             int64_t klen) {
     constexpr int BM = 32 * WM;
@@ -209,10 +214,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     // loads slab [k0, k0 + 16); the advancing contexts stand at k0 on entry and at k0 + 16 on exit
     auto fetch = [&](int64_t k0) {
         if constexpr (A_KG_FAST) {
-            const bool kok = k0 + (tid % A_KGS) * AV < kend;                 // K is a multiple of AV
+            const bool kok = FULLK || k0 + (tid % A_KGS) * AV < kend;        // K is a multiple of AV
 #pragma unroll
             for (int e = 0; e < A_PER; e++) {
-                if (kok && a_ok[e]) {
+                if (FULLK || (kok && a_ok[e])) {        // rows past M are clamped to row 0 and never stored
                     a.at_vec(arow[e], acol[0], areg[e]);
                 } else {
 #pragma unroll
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
             for (int e = 0; e < A_PER; e++) {
                 const int t = tid + e * GEMM_THREADS;
                 const int64_t k = k0 + (t / BM) * AV;                       // K is a multiple of AV
-                if (t < A_TASKS_ALL && a_ok[0] && k < kend) {
+                if ((A_TASKS_ALL % GEMM_THREADS == 0 || t < A_TASKS_ALL) && (FULLK || (a_ok[0] && k < kend))) {
                     a.at_vec(arow[0], acol[e], areg[e]);
                 } else {
 #pragma unroll
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
             for (int e = 0; e < A_PER; e++) {
                 const int t = tid + e * GEMM_THREADS;
                 const int64_t k = k0 + (A_K_LANES ? t % GEMM_BK : t / A_MG);
-                if (t < A_TASKS_ALL && a_ok[0] && k < kend) {
+                if ((A_TASKS_ALL % GEMM_THREADS == 0 || t < A_TASKS_ALL) && (FULLK || (a_ok[0] && k < kend))) {
                     a.at_vec(arow[0], acol[e], areg[e]);
                 } else {
 #pragma unroll
@@ -248,23 +253,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
             }
         } else if constexpr (AL::kInnerFast) {
             const int64_t k = k0 + tid % GEMM_BK;
-            const bool kok = k < kend;
+            const bool kok = FULLK || k < kend;
 #pragma unroll
-            for (int e = 0; e < A_PER; e++) areg[e][0] = (kok && a_ok[e]) ? a.at(arow[e], acol[0]) : 0.f;
+            for (int e = 0; e < A_PER; e++) areg[e][0] = (FULLK || (kok && a_ok[e])) ? a.at(arow[e], acol[0]) : 0.f;
             a.advance_col(acol[0], GEMM_BK);
         } else {
 #pragma unroll
             for (int e = 0; e < A_PER; e++) {
                 const int64_t k = k0 + tid / BM + e * A_KSTEP;
-                areg[e][0] = (a_ok[0] && k < kend) ? a.at(arow[0], acol[e]) : 0.f;
+                areg[e][0] = (FULLK || (a_ok[0] && k < kend)) ? a.at(arow[0], acol[e]) : 0.f;
                 a.advance_col(acol[e], GEMM_BK);
             }
         }
         if constexpr (BV > 1 && !BL::kInnerFast) {
-            const bool kok = k0 + (tid % B_KGS) * BV < kend;                 // K is a multiple of BV
+            const bool kok = FULLK || k0 + (tid % B_KGS) * BV < kend;        // K is a multiple of BV
 #pragma unroll
             for (int e = 0; e < B_PER; e++) {
-                if (kok && b_ok[e]) {
+                if ((FULLK && (B_TASKS_ALL % GEMM_THREADS == 0 || tid + e * GEMM_THREADS < B_TASKS_ALL)) || (kok && b_ok[e])) {
                     b.at_vec(brow[0], bcol[e], breg[e]);
                 } else {
 #pragma unroll
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
             for (int e = 0; e < B_PER; e++) {
                 const int t = tid + e * GEMM_THREADS;
                 const int64_t k = k0 + t / B_NG;
-                if (t < B_TASKS_ALL && b_ok[0] && k < kend) {
+                if ((B_TASKS_ALL % GEMM_THREADS == 0 || t < B_TASKS_ALL) && (FULLK || (b_ok[0] && k < kend))) {
                     b.at_vec(brow[e], bcol[0], breg[e]);
                 } else {
 #pragma unroll
@@ -289,14 +294,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
 #pragma unroll
             for (int e = 0; e < B_PER; e++) {
                 const int64_t k = k0 + tid / BN + e * B_KSTEP;
-                breg[e][0] = (b_ok[0] && k < kend) ? b.at(brow[e], bcol[0]) : 0.f;
+                breg[e][0] = (FULLK || (b_ok[0] && k < kend)) ? b.at(brow[e], bcol[0]) : 0.f;
                 b.advance_row(brow[e], GEMM_BK);
             }
         } else {
             const int64_t k = k0 + tid % GEMM_BK;
-            const bool kok = k < kend;
+            const bool kok = FULLK || k < kend;
 #pragma unroll
-            for (int e = 0; e < B_PER; e++) breg[e][0] = (kok && b_ok[e]) ? b.at(brow[0], bcol[e]) : 0.f;
+            for (int e = 0; e < B_PER; e++) breg[e][0] = (FULLK || (kok && b_ok[e])) ? b.at(brow[0], bcol[e]) : 0.f;
             b.advance_row(brow[0], GEMM_BK);
         }
     };
@@ -422,13 +427,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
     }
 }
 
+// a loader whose k range depends on the tile says on the host whether every tile's range is whole slabs
+template <class L, class = void>
+struct has_full_slabs : std::false_type {};
+template <class L>
+struct has_full_slabs<L, std::void_t<decltype(std::declval<const L &>().full_slabs())>> : std::true_type {};
+
 template <class AL, class BL, class EP, int AV, int BV>
 inline int launch_gemm_v(const AL &a, const BL &b, const EP &ep, int64_t M, int N, int64_t K, int64_t klen, dim3 grid,
                          bool small_m, bool narrow, hipStream_t s, const char *what) {
+    static const bool no_fullk = getenv("PPO2HIP_GEMM_CHECKED") != nullptr;
+    bool fullk = K > 0 && K % GEMM_BK == 0 && !no_fullk;       // klen is a multiple of 16 by construction
+    if constexpr (tile_k<AL>::value) {
+        if constexpr (has_full_slabs<AL>::value) fullk = fullk && a.full_slabs();
+        else fullk = false;
+    }
+    // the wide, well-shaped products are the ones that matter; the 64-row tiles keep the checked loads only
     if (small_m)
         hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 2, 1, AV, BV>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
+    else if (narrow && fullk)
+        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 1, AV, BV, true>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
     else if (narrow)
         hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 1, AV, BV>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
+    else if (fullk)
+        hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 2, AV, BV, true>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
     else
         hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 2, AV, BV>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
     return check_launch(what);
