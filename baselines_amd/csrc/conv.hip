@@ -115,9 +115,13 @@ struct Im2colT {   // A(i = k, kk = m), row `ones_row` = 1 after the epilogue's 
     __device__ Col col(int64_t m) const { return patch_row(c.g, m); }
     __device__ void advance_col(Col &p, int d) const {      // d output pixels further on
         const ConvGeom &g = c.g;
-        // d = dq OW + dr pixels on: dq rows and dr columns, then at most one carry each way (uniform tests, no per-lane loops)
+        // d = dq OW + dr pixels on: dq rows and dr columns, then at most one carry each way (uniform tests, no per-lane
+        // loops); the patch offset moves by sums of wave-uniform constants — no multiplication per step
         const int dq = d / g.OW, dr = d - dq * g.OW;
         if (dq + 1 <= g.OH) {
+            const int step = (dq * g.S * g.IW + dr * g.S) * g.Cin;             // dq rows down, dr columns right
+            const int carry_w = (g.S * g.IW - g.OW * g.S) * g.Cin;             // back OW columns, one row down
+            const int carry_h = (g.IH * g.IW - g.OH * g.S * g.IW) * g.Cin;     // back OH rows, one image on
             p.ow += dr;
             p.oh += dq;
             const bool wc = p.ow >= g.OW;
@@ -126,11 +130,12 @@ struct Im2colT {   // A(i = k, kk = m), row `ones_row` = 1 after the epilogue's 
             const bool wr = p.oh >= g.OH;
             p.oh -= wr ? g.OH : 0;
             p.b += wr ? 1 : 0;
-        } else {
-            p.ow += d;
-            while (p.ow >= g.OW) { p.ow -= g.OW; p.oh++; }
-            while (p.oh >= g.OH) { p.oh -= g.OH; p.b++; }
+            p.base += step + (wc ? carry_w : 0) + (wr ? carry_h : 0);
+            return;
         }
+        p.ow += d;
+        while (p.ow >= g.OW) { p.ow -= g.OW; p.oh++; }
+        while (p.oh >= g.OH) { p.oh -= g.OH; p.b++; }
         p.base = (((int64_t)p.b * g.IH + p.oh * g.S) * g.IW + p.ow * g.S) * g.Cin;
     }
     __device__ float at(const Row &r, const Col &p) const { return r < 0 ? (U8 ? 255.f : 1.f) : c.at_off(p.base, r); }
