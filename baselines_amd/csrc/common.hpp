@@ -71,7 +71,7 @@ __host__ __device__ inline int64_t tm_offset(int64_t s, int T, int E) {
 // Sample numbers that arrive from a caller's index list are checked where they are used: one outside [0, limit) raises
 // bit `bit` of the device's fault word (read and cleared by ppo2hip_take_faults) and is replaced by sample 0, so that a
 // stale list is reported instead of faulting the GPU or gathering garbage silently.
-constexpr unsigned kFaultIndexRange = 1u, kFaultComposeRange = 2u;
+constexpr unsigned kFaultIndexRange = 1u, kFaultComposeRange = 2u, kFaultGridSync = 4u;
 __device__ inline int64_t checked_sample(int64_t smp, int64_t limit, unsigned *fault, unsigned bit = kFaultIndexRange) {
     if ((uint64_t)smp >= (uint64_t)limit) {
         atomicOr(fault, bit);

@@ -211,6 +211,14 @@ int lstm_gates_bwd(float *gates, int64_t z_stride, const float *c, const float *
 
 // one launch per step and direction (product + element-wise half) for the widths lstm_step_fused_width() names
 bool lstm_step_fused_width(int nh);
+// all T steps in one launch (the workgroups of a group of 16 envs hand h round through tagged 64-bit words);
+// xchg: lstm_seq_xchg_bytes(nenv, nh) of device scratch (sized for the backward launch, which hands the gate gradients round)
+bool lstm_seq_ok(int nenv, int nh);
+size_t lstm_seq_xchg_bytes(int nenv, int nh);
+int lstm_seq_fwd(float *z, const float *wh, float *hm, float *cm, int nenv, int T, int nh, float *c, float *h, float *state_out,
+                 const uint8_t *masks, void *xchg, hipStream_t s);
+int lstm_seq_bwd(float *gates, const float *wh, const float *c, const float *cm, const float *dh_head, const uint8_t *masks,
+                 int nenv, int T, int nh, void *xchg, hipStream_t s);
 int lstm_step_fwd(float *z, int64_t z_stride, const float *wh, const float *hm, const float *cm, int64_t s_stride, int nenv,
                   int nh, float *c, float *h, float *state_out, const uint8_t *mask_next, int64_t mask_stride, float *cm_next,
                   float *hm_next, hipStream_t s);

@@ -3,6 +3,9 @@
 // matrix products (x wx for all steps at once, h wh per step, and their gradients) run on the
 // MFMA GEMM; these kernels do the masking, the gate non-linearities and their backward.
 // Rows are env-major: row(e, t) = e * T + t (batch_to_seq, a2c/utils.py:70-75).
+#include <atomic>
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace ppo2hip {
@@ -235,6 +238,306 @@ static int launch_step_bwd(float *gates, const float *dz_next, int64_t z_stride,
     hipLaunchKernelGGL(lstm_step_bwd_kernel<NH>, dim3(NH / 16, (unsigned)ceil_div(nenv, 16)), dim3(256), 0, s, gates, dz_next,
                        z_stride, wh, c, cm, dh_head, s_stride, dcm_carry, mask_next, mask_stride, nenv);
     return check_launch("lstm_step_bwd_kernel");
+}
+
+// ---------------------------------------------------------------------------------------
+// All T steps of the forward recurrence in ONE launch.  A step's kernel above runs 5 us and waits 2-4 us for the step
+// before it to drain; here a workgroup keeps its tile (16 envs x 16 units) for the whole sequence: its slice of wh stays
+// in registers (loaded once, not once per step), its cell state c stays in the owning thread's register, and only h
+// travels — the sixteen workgroups of an env group each publish their 16 x 16 piece of the masked h_t and read the whole
+// row block back; env groups never wait for each other.
+// The hand-over is one hop: a value travels as a 64-bit word {float bits, tag} written and read with agent-scope atomic
+// accesses (they go past the per-XCD caches), tag = launch tag + step, so a reader knows from the word itself whether
+// it holds this step's value and simply reads again until all its sixteen words do — no arrival counter, no store
+// drain, no second round trip.  Two word buffers alternate by step parity: nobody can write step t + 2 before every
+// workgroup of the group has published t + 1, i.e. has finished reading t.  The buffers are zeroed before the launch
+// and tags never are zero.  Every wait is bounded: a lane that gives up raises the library's fault word and carries on
+// with what it has.  All (NH / 16) x ceil(nenv / 16) workgroups must be resident together: at most one per CU is
+// asked for.
+// ---------------------------------------------------------------------------------------
+struct LstmSeqFwd {
+    float *z;                 // [nenv][T][4 NH] gate pre-activations x wx + b in, activated gates out
+    const float *wh;
+    float *hm, *cm;           // [nenv][T][NH] masked previous states; row t = 0 filled by the caller
+    float *c, *h;             // [nenv][T][NH]
+    float *state_out;         // [nenv][2 NH] or null
+    const uint8_t *masks;     // [nenv][T]
+    unsigned long long *xchg; // [2][nenv][NH] words, zeroed by the caller
+    unsigned *fault;
+    unsigned tag0;            // word tags of this launch: tag0 + t, never 0
+    int nenv, T;
+};
+
+template <int NH>
+__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqFwd a) {
+    constexpr int KL = NH / 16;
+    __shared__ float part[4][4][16][17];
+    __shared__ float hs[16][NH + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int u0 = blockIdx.x * 16, e0 = blockIdx.y * 16;
+    const int kb = wave * (NH / 4) + lk * KL;
+    const int64_t s_stride = (int64_t)a.T * NH, z_stride = (int64_t)a.T * 4 * NH;
+    float b[KL][4];
+#pragma unroll
+    for (int s = 0; s < KL; s++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) b[s][g] = a.wh[(int64_t)(kb + s) * (4 * NH) + g * NH + u0 + li];
+    const int el = tid >> 4, ul = tid & 15, e = e0 + el, j = u0 + ul;
+    const bool live = e < a.nenv;
+    const int ee = live ? e : a.nenv - 1;
+    const int64_t sr0 = (int64_t)(live ? e : 0) * s_stride + j;
+    float c_prev = live ? a.cm[sr0] : 0.f;             // step 0's masked state; afterwards this thread's own
+    bool gave_up = false;
+    for (int t = 0; t < a.T; t++) {
+        // what the step needs besides h goes out first and arrives while h is waited for
+        float *zr = a.z + (int64_t)(live ? e : 0) * z_stride + (int64_t)t * 4 * NH;
+        float zx[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) zx[g] = zr[g * NH + j];
+        const float keep = (t + 1 < a.T && live && a.masks[(int64_t)e * a.T + t + 1]) ? 0.f : 1.f;
+        // hm_t of the group's 16 envs, all NH units: thread (el, ul) fetches units ul + 16 p of env el — sixteen lanes
+        // read one 128-byte run — and the block goes through LDS into operand order
+        if (t == 0) {
+            const float *hp = a.hm + (int64_t)ee * s_stride + ul;
+#pragma unroll
+            for (int p = 0; p < KL; p++) hs[el][ul + 16 * p] = hp[16 * p];
+        } else {
+            unsigned long long *xp = a.xchg + ((int64_t)(t & 1) * a.nenv + ee) * NH + ul;
+            const unsigned want = a.tag0 + (unsigned)t;
+            unsigned long long w[KL];
+            int tries = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int p = 0; p < KL; p++) w[p] = __hip_atomic_load(xp + 16 * p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int p = 0; p < KL; p++) ok = ok && (unsigned)(w[p] >> 32) == want;
+                if (ok || gave_up) break;
+                if (++tries > (1 << 18)) {
+                    atomicOr(a.fault, kFaultGridSync);
+                    gave_up = true;
+                    break;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < KL; p++) hs[el][ul + 16 * p] = __uint_as_float((unsigned)w[p]);
+        }
+        __syncthreads();
+        float av[KL];
+#pragma unroll
+        for (int q = 0; q < KL; q++) av[q] = hs[li][kb + q];
+        lf32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[g] = lf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KL; s++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) acc[g] = LSTM_MFMA16(av[s], b[s][g], acc[g]);
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[wave][g][4 * lk + r][li] = acc[g][r];
+        __syncthreads();
+        if (live) {
+            float zv[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                zv[g] = zx[g] + ((part[0][g][el][ul] + part[1][g][el][ul]) + (part[2][g][el][ul] + part[3][g][el][ul]));
+            const float i = sigmoidf(zv[0]), f = sigmoidf(zv[1]), o = sigmoidf(zv[2]), u = tanhf(zv[3]);
+            const int64_t sr = sr0 + (int64_t)t * NH;
+            const float cn = f * c_prev + i * u;
+            const float hn = o * tanhf(cn);
+            if (t + 1 < a.T) {
+                // the travelling value first: everything else of this step can trail behind it
+                const float hk = hn * keep;
+                const unsigned long long word = ((unsigned long long)(a.tag0 + (unsigned)(t + 1)) << 32) | __float_as_uint(hk);
+                __hip_atomic_store(a.xchg + ((int64_t)((t + 1) & 1) * a.nenv + e) * NH + j, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c_prev = cn * keep;
+                a.cm[sr + NH] = c_prev;
+                a.hm[sr + NH] = hk;
+            } else if (a.state_out) {
+                a.state_out[(int64_t)e * 2 * NH + j] = cn;
+                a.state_out[(int64_t)e * 2 * NH + NH + j] = hn;
+            }
+            zr[j] = i; zr[NH + j] = f; zr[2 * NH + j] = o; zr[3 * NH + j] = u;
+            a.c[sr] = cn;
+            a.h[sr] = hn;
+        }
+        __syncthreads();          // the partial tiles are free for the next step
+    }
+}
+
+template <int NH>
+static int launch_seq_fwd(const LstmSeqFwd &a, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel<NH>, dim3(NH / 16, (unsigned)ceil_div(a.nenv, 16)), dim3(256), 0, s, a);
+    return check_launch("lstm_seq_fwd_kernel");
+}
+
+// the whole-sequence kernels need all their workgroups resident at once: one per CU is what they may count on
+bool lstm_seq_ok(int nenv, int nh) {
+    static const bool off = getenv("PPO2HIP_LSTM_SEQ_OFF") != nullptr;
+    return !off && (nh == 64 || nh == 128 || nh == 256 || nh == 512) && (int64_t)(nh / 16) * ceil_div(nenv, 16) <= 256;
+}
+size_t lstm_seq_xchg_bytes(int nenv, int nh) { return (size_t)2 * (nh / 16) * nenv * nh * sizeof(unsigned long long); }
+
+// tags of a launch: T + 1 consecutive values, never 0, different from launch to launch
+static unsigned next_seq_tag(int T) {
+    static std::atomic<unsigned> g_tag{1u};
+    unsigned t = g_tag.fetch_add((unsigned)T + 1u);
+    if (t > 0xffffffffu - 2u * ((unsigned)T + 1u)) { g_tag.store(1u); t = g_tag.fetch_add((unsigned)T + 1u); }
+    return t;
+}
+
+int lstm_seq_fwd(float *z, const float *wh, float *hm, float *cm, int nenv, int T, int nh, float *c, float *h, float *state_out,
+                 const uint8_t *masks, void *xchg, hipStream_t s) {
+    if (nenv <= 0 || T <= 0) return 0;
+    unsigned *fault = fault_word();
+    if (!fault) return PPO2HIP_EINVAL;
+    PPO2HIP_CHECK_HIP(hipMemsetAsync(xchg, 0, (size_t)2 * nenv * nh * sizeof(unsigned long long), s));
+    LstmSeqFwd a{z, wh, hm, cm, c, h, state_out, masks, (unsigned long long *)xchg, fault, next_seq_tag(T), nenv, T};
+    switch (nh) {
+        case 64: return launch_seq_fwd<64>(a, s);
+        case 128: return launch_seq_fwd<128>(a, s);
+        case 256: return launch_seq_fwd<256>(a, s);
+        case 512: return launch_seq_fwd<512>(a, s);
+        default: break;
+    }
+    set_error("lstm_seq_fwd: no instance for nlstm=%d", nh);
+    return PPO2HIP_EUNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------
+// All T steps of the backward recurrence in one launch, same hand-over as the forward.  What travels is not the gate
+// gradients of a step (16 envs x 4 NH per group) but what each workgroup's own 64 gate columns contribute to
+// dhm = dz wh^T for ALL NH units — a 16 x NH tile per workgroup, computed as soon as its gate gradients exist, from its
+// slice of wh in registers — so a workgroup reads 16 producers x (16 envs x 16 units) words per step, the same volume
+// as the forward, and adds them in producer order.  dcm stays in the owning thread's register.
+// ---------------------------------------------------------------------------------------
+struct LstmSeqBwd {
+    float *gates;             // [nenv][T][4 NH] activated gates in, gate gradients out
+    const float *wh;
+    const float *c, *cm;      // [nenv][T][NH]
+    const float *dh_head;     // [nenv][T][NH]
+    const uint8_t *masks;     // [nenv][T]
+    unsigned long long *xchg; // [2][NH / 16][nenv][NH] words, zeroed by the caller
+    unsigned *fault;
+    unsigned tag0;
+    int nenv, T;
+};
+
+template <int NH>
+__global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwd a) {
+    constexpr int NUB = NH / 16;          // workgroups per env group = producers of a sum
+    constexpr int NBW = NH / 64;          // 16-unit blocks of the partial product per wave
+    __shared__ float dzs[16][68];         // this workgroup's gate gradients of the step, [env][gate 16 + unit]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int ub = blockIdx.x, u0 = ub * 16, e0 = blockIdx.y * 16;
+    const int64_t s_stride = (int64_t)a.T * NH, z_stride = (int64_t)a.T * 4 * NH;
+    // B operand of the partial product: B[k][n] = wh[unit n][column of local k], local k = gate 16 + unit
+    float bw[16][NBW];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const int kl = 4 * s + lk, col = (kl >> 4) * NH + u0 + (kl & 15);
+#pragma unroll
+        for (int nb = 0; nb < NBW; nb++) bw[s][nb] = a.wh[(int64_t)(16 * (NBW * wave + nb) + li) * (4 * NH) + col];
+    }
+    const int el = tid >> 4, ul = tid & 15, e = e0 + el, j = u0 + ul;
+    const bool live = e < a.nenv;
+    const int ee = live ? e : 0;
+    float dcm = 0.f;
+    bool gave_up = false;
+    for (int t = a.T - 1; t >= 0; t--) {
+        const bool last = t == a.T - 1;
+        const int64_t sr = (int64_t)ee * s_stride + (int64_t)t * NH + j;
+        float *zr = a.gates + (int64_t)ee * z_stride + (int64_t)t * 4 * NH;
+        // the step's own inputs first; they arrive while the sums are waited for
+        const float gi = zr[j], gf = zr[NH + j], go = zr[2 * NH + j], gu = zr[3 * NH + j];
+        const float cv = a.c[sr], cmv = a.cm[sr], dhh = a.dh_head[sr];
+        const float keep = (!last && a.masks[(int64_t)ee * a.T + t + 1]) ? 0.f : 1.f;
+        float dhm = 0.f;
+        if (!last) {
+            unsigned long long *xp = a.xchg + (((int64_t)(t & 1) * NUB) * a.nenv + ee) * NH + j;
+            const unsigned want = a.tag0 + (unsigned)t;
+            unsigned long long w[NUB];
+            int tries = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int p = 0; p < NUB; p++)
+                    w[p] = __hip_atomic_load(xp + (int64_t)p * a.nenv * NH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int p = 0; p < NUB; p++) ok = ok && (unsigned)(w[p] >> 32) == want;
+                if (ok || gave_up) break;
+                if (++tries > (1 << 18)) {
+                    atomicOr(a.fault, kFaultGridSync);
+                    gave_up = true;
+                    break;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NUB; p++) dhm += __uint_as_float((unsigned)w[p]);
+        }
+        const float dh = dhh + dhm * keep;
+        const float tc = tanhf(cv);
+        const float dc = (last ? 0.f : dcm * keep) + dh * go * (1.f - tc * tc);
+        const float d0 = dc * gu * gi * (1.f - gi), d1 = dc * cmv * gf * (1.f - gf), d2 = dh * tc * go * (1.f - go),
+                    d3 = dc * gi * (1.f - gu * gu);
+        dcm = dc * gf;
+        if (t > 0) {
+            dzs[el][ul] = live ? d0 : 0.f; dzs[el][16 + ul] = live ? d1 : 0.f;
+            dzs[el][32 + ul] = live ? d2 : 0.f; dzs[el][48 + ul] = live ? d3 : 0.f;
+        }
+        if (live) { zr[j] = d0; zr[NH + j] = d1; zr[2 * NH + j] = d2; zr[3 * NH + j] = d3; }
+        if (t > 0) {
+            __syncthreads();
+            // what these 64 gate columns add to dhm of step t - 1, for all NH units: out before anything else
+            lf32x4 acc[NBW];
+#pragma unroll
+            for (int nb = 0; nb < NBW; nb++) acc[nb] = lf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const float av = dzs[li][4 * s + lk];
+#pragma unroll
+                for (int nb = 0; nb < NBW; nb++) acc[nb] = LSTM_MFMA16(av, bw[s][nb], acc[nb]);
+            }
+            const unsigned long long tag = (unsigned long long)(a.tag0 + (unsigned)(t - 1)) << 32;
+            unsigned long long *op = a.xchg + (((int64_t)((t - 1) & 1) * NUB + ub) * a.nenv) * NH;
+#pragma unroll
+            for (int nb = 0; nb < NBW; nb++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int env = e0 + 4 * lk + r;
+                    if (env < a.nenv)
+                        __hip_atomic_store(op + (int64_t)env * NH + 16 * (NBW * wave + nb) + li, tag | __float_as_uint(acc[nb][r]),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            __syncthreads();          // the gradient tile is free for the next step
+        }
+    }
+}
+
+template <int NH>
+static int launch_seq_bwd(const LstmSeqBwd &a, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel<NH>, dim3(NH / 16, (unsigned)ceil_div(a.nenv, 16)), dim3(256), 0, s, a);
+    return check_launch("lstm_seq_bwd_kernel");
+}
+
+int lstm_seq_bwd(float *gates, const float *wh, const float *c, const float *cm, const float *dh_head, const uint8_t *masks,
+                 int nenv, int T, int nh, void *xchg, hipStream_t s) {
+    if (nenv <= 0 || T <= 0) return 0;
+    unsigned *fault = fault_word();
+    if (!fault) return PPO2HIP_EINVAL;
+    PPO2HIP_CHECK_HIP(hipMemsetAsync(xchg, 0, lstm_seq_xchg_bytes(nenv, nh), s));
+    LstmSeqBwd a{gates, wh, c, cm, dh_head, masks, (unsigned long long *)xchg, fault, next_seq_tag(T), nenv, T};
+    switch (nh) {
+        case 64: return launch_seq_bwd<64>(a, s);
+        case 128: return launch_seq_bwd<128>(a, s);
+        case 256: return launch_seq_bwd<256>(a, s);
+        case 512: return launch_seq_bwd<512>(a, s);
+        default: break;
+    }
+    set_error("lstm_seq_bwd: no instance for nlstm=%d", nh);
+    return PPO2HIP_EUNSUPPORTED;
 }
 
 // widths with a compiled instance (the loops over k are unrolled per width)

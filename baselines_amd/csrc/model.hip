@@ -322,6 +322,7 @@ struct CnnBuf {
     float *Y1, *Y2, *Y3, *F, *PI, *VF;
     float *Z, *HM, *CM, *C, *Hs, *S0;          // LSTM: gates [B,4nh], masked prev states, states, gathered initial state
     float *ZP;                                 // partial products of one step's hm wh, [kLstmFwdParts][nenv, 4nh]
+    void *XCHG;                                // hand-over words of the whole-sequence LSTM launches
     float *ZX, *ZH, *CN, *RX, *RH, *RC;        // layer-normalised cell: normalised x wx / hm wh / c rows and their 1/std
     float *dPI, *dVF, *dF, *dY3, *dY2, *dY1, *DH, *dhm, *dcm;
     float *DZX, *DZH, *DL;                     // ... gradients w.r.t. the raw products and w.r.t. LN(c)
@@ -344,6 +345,7 @@ static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver 
         w.C = c.take<float>(B * k.nh); w.Hs = c.take<float>(B * k.nh);
         w.S0 = c.take<float>((int64_t)nenv * 2 * k.nh);
         w.ZP = c.take<float>((int64_t)kLstmFwdParts * nenv * 4 * k.nh);
+        w.XCHG = c.take<uint8_t>((int64_t)lstm_seq_xchg_bytes(nenv, k.nh));
         if (k.ln) {
             w.ZX = c.take<float>(B * 4 * k.nh); w.ZH = c.take<float>(B * 4 * k.nh); w.CN = c.take<float>(B * k.nh);
             w.RX = c.take<float>(B); w.RH = c.take<float>(B); w.RC = c.take<float>(B);
@@ -442,6 +444,9 @@ static int lstm_forward_all(const ppo2hip_policy_desc &d, const Layout &L, const
     // keeps the product on the GEMM and the gates in a launch of their own
     const char *steps_env = getenv("PPO2HIP_LSTM_STEPS");
     const bool fused_steps = lstm_step_fused_width(nh) && (uintptr_t)wh % 16 == 0 && !(steps_env && std::strcmp(steps_env, "split") == 0);
+    // the whole sequence in one launch where its workgroups fit the chip together (PPO2HIP_LSTM_SEQ_OFF=1: a launch per step)
+    if (fused_steps && T > 1 && lstm_seq_ok(nenv, nh))
+        return lstm_seq_fwd(w.Z, wh, w.HM, w.CM, nenv, T, nh, w.C, w.Hs, state_out, masks, w.XCHG, s);
     for (int t = 0; t < T; t++) {
         const int64_t o1 = (int64_t)t * nh, o4 = (int64_t)t * 4 * nh;
         const bool last = t == T - 1;
@@ -575,7 +580,9 @@ static int cnn_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
         } else {
         const char *steps_env = getenv("PPO2HIP_LSTM_STEPS");
         const bool fused_steps = lstm_step_fused_width(nh) && (uintptr_t)wh % 16 == 0 && !(steps_env && std::strcmp(steps_env, "split") == 0);
-        for (int t = T - 1; fused_steps && t >= 0; t--) {
+        const bool seq = fused_steps && T > 1 && lstm_seq_ok(nenv, nh);
+        if (seq && (rc = lstm_seq_bwd(w.Z, wh, w.C, w.CM, w.DH, w.MASK, nenv, T, nh, w.XCHG, s))) return rc;
+        for (int t = T - 1; fused_steps && !seq && t >= 0; t--) {
             // dhm of step t + 1's gate gradients and step t's gate gradients in one launch
             const bool last = t == T - 1;
             if ((rc = lstm_step_bwd(w.Z + (int64_t)t * 4 * nh, last ? nullptr : w.Z + (int64_t)(t + 1) * 4 * nh, (int64_t)T * 4 * nh, wh,
