@@ -345,7 +345,10 @@ static void carve_cnn(const ppo2hip_policy_desc &d, int64_t B, int nenv, Carver 
         w.C = c.take<float>(B * k.nh); w.Hs = c.take<float>(B * k.nh);
         w.S0 = c.take<float>((int64_t)nenv * 2 * k.nh);
         w.ZP = c.take<float>((int64_t)kLstmFwdParts * nenv * 4 * k.nh);
-        w.XCHG = c.take<uint8_t>((int64_t)lstm_seq_xchg_bytes(nenv, k.nh));
+        {   // hand-over words of the whole-sequence launches: only env counts those launches take (all workgroups resident)
+            const int seq_envs = nenv < 65536 / k.nh ? nenv : 65536 / k.nh;
+            w.XCHG = c.take<uint8_t>(k.ln ? 0 : (int64_t)lstm_seq_xchg_bytes(seq_envs, k.nh));
+        }
         if (k.ln) {
             w.ZX = c.take<float>(B * 4 * k.nh); w.ZH = c.take<float>(B * 4 * k.nh); w.CN = c.take<float>(B * k.nh);
             w.RX = c.take<float>(B); w.RH = c.take<float>(B); w.RC = c.take<float>(B);

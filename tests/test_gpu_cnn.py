@@ -187,3 +187,61 @@ def test_uint8_conv_kernels_agree_with_the_float32_route(tmp_path):
         ref = b[off:off + n]
         assert np.abs(a[off:off + n] - ref).max() <= 2e-6 * max(np.abs(ref).max(), 1e-6), name
     np.testing.assert_allclose(out["pieces"]["losses"][:5], out["plain"]["losses"][:5], rtol=2e-6, atol=1e-7)
+
+
+_LSTM_ROUTE_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from baselines_amd import hip, _lib
+hwc, nact, T, E, nenv_mb, nlstm = (36, 36, 2), 4, 12, 48, 40, 128
+spec = hip.PolicySpec(_lib.POLICY_CNN_LSTM, _lib.DIST_CATEGORICAL, nact, 1, ob_hwc=hwc, nlstm=nlstm)
+g = torch.Generator(device="cuda"); g.manual_seed(5)
+theta = (torch.randn(spec.nparams, device="cuda", generator=g) * 0.05)
+obs = torch.randint(0, 256, (T, E) + hwc, device="cuda", generator=g, dtype=torch.uint8)
+f = lambda *s: torch.randn(*s, device="cuda", generator=g)
+acts = torch.randint(0, nact, (T, E), device="cuda", generator=g, dtype=torch.int32)
+rets, vals, nlp, advs = f(T, E, 1), f(T, E, 1), f(T, E).abs() + 1.0, f(T, E)
+dones = (torch.rand(T, E, device="cuda", generator=g) < 0.15)
+states = f(E, 2 * nlstm) * 0.3
+rref = hip.RolloutRef(spec, obs, acts, rets, vals, nlp, advs, T, E, dones, states)
+envs = torch.randperm(E, device="cuda", generator=g)[:nenv_mb].to(torch.int32)
+idx = (envs[:, None].to(torch.int64) * T + torch.arange(T, device="cuda")[None, :]).to(torch.int32).reshape(-1).contiguous()
+B = nenv_mb * T
+stats = hip.adv_stats(rref.keep[5], idx, B, 1, T, E)
+grads = torch.zeros(spec.nparams, device="cuda"); losses = torch.zeros(8, device="cuda")
+ws = torch.empty(spec.grad_workspace_bytes(B), dtype=torch.uint8, device="cuda")
+hip.ppo_grad(spec, _lib.LossDesc(0.01, 0.5, 0.5, 1), theta, rref, idx, B, stats, 0.1, 1.0 / B, grads, losses, ws,
+             mb_envs=envs, nsteps_mb=T)
+hip.take_faults()
+torch.cuda.synchronize()
+np.savez(sys.argv[2], grads=grads.cpu().numpy(), losses=losses.cpu().numpy())
+"""
+
+
+def test_lstm_sequence_kernels_agree_with_one_launch_per_step(tmp_path):
+    """Plain LSTM recurrence: the whole-sequence launches (workgroups handing h and partial dhm sums round) against one
+    launch per step and direction, same inputs, two fresh processes (the switch is read once per process).  40 envs leave a
+    part-filled env group.  The forward adds the same terms in the same order; the backward adds the sixteen producers'
+    partial sums of dhm in another order than the per-step kernel's four wave sums: 5e-6 of each variable's largest gradient."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "route.py"
+    script.write_text(_LSTM_ROUTE_SCRIPT)
+    out = {}
+    for name, env in (("seq", {}), ("steps", {"PPO2HIP_LSTM_SEQ_OFF": "1"})):
+        e = dict(os.environ)
+        e.update(env)
+        path = str(tmp_path / (name + ".npz"))
+        subprocess.run([sys.executable, str(script), root, path], check=True, env=e, timeout=240)
+        out[name] = np.load(path)
+    from baselines_amd import hip as h, _lib
+    spec = h.PolicySpec(_lib.POLICY_CNN_LSTM, _lib.DIST_CATEGORICAL, 4, 1, ob_hwc=(36, 36, 2), nlstm=128)
+    a, b = out["seq"]["grads"], out["steps"]["grads"]
+    assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
+    for name, off, shp in spec.vars:
+        n = int(np.prod(shp))
+        ref = b[off:off + n]
+        assert np.abs(a[off:off + n] - ref).max() <= 5e-6 * max(np.abs(ref).max(), 1e-6), name
+    np.testing.assert_allclose(out["seq"]["losses"][:5], out["steps"]["losses"][:5], rtol=2e-6, atol=1e-7)
