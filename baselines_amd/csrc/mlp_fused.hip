@@ -600,9 +600,22 @@ __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(Finaliz
             pidx = out - f.grads;
             th = ad.theta[pidx]; mi = ad.m[pidx]; vi = ad.v[pidx];
         }
+        // this thread's slabs grp, grp + 16, ...: all loads in flight before the first add (a loop of load-then-add runs one
+        // memory round trip per slab), summed in slab order
         float s = 0.f;
-        if (p)
-            for (int z = grp; z < nz; z += kFinGroups) s += p[(int64_t)z * f.slab_elems];
+        if (p) {
+            constexpr int U = 10;
+            for (int z0 = grp; z0 < nz; z0 += kFinGroups * U) {
+                float x[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int z = z0 + u * kFinGroups;
+                    x[u] = z < nz ? p[(int64_t)z * f.slab_elems] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) s += x[u];
+            }
+        }
         part[grp][lane] = s;
         __syncthreads();
         float t = 0.f;
