@@ -15,6 +15,10 @@
 // k-steps (the k order inside a run is permuted: lane half h takes bytes 16 h .. 16 h + 15; the weight image is laid
 // out to match).  A wave owns 32 consecutive output pixels and all 32 output channels; the three-piece weight image of
 // the whole layer (48 KB for K = 256) sits in LDS in fragment order, one conflict-free ds_read_b128 per product.
+//
+// Both kernels of this file can take a list of frame numbers (`rows`) and read a minibatch's frames where they lie in the
+// rollout instead of from a gathered copy; the forward can also leave one word of "output > 0" bits per output pixel
+// (`relu_bits`), which the next layer's input gradient reads for the rectifier's derivative instead of the activations.
 #include <cstdlib>
 
 #include "kernels.hpp"
