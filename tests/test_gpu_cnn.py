@@ -45,7 +45,7 @@ def _check(hip, spec, params, oracle, o_losses, theta, grads, losses, upstream=T
 # pieces) — 24 frames end in a part-filled 128-pixel tile and an odd number of pixel groups per frame; 300 frames make the
 # workgroups of both kernels walk several tiles / frames each, unevenly
 @pytest.mark.parametrize("hwc,nact,T,E,B", [((36, 36, 2), 4, 4, 6, 20), ((44, 52, 4), 6, 3, 8, 24), ((84, 84, 4), 6, 2, 8, 16),
-                                            ((84, 84, 4), 6, 3, 100, 300)])
+                                            ((84, 84, 4), 6, 3, 100, 300), ((84, 84, 4), 6, 1, 3, 3)])
 def test_cnn_policy_grad(hip, hwc, nact, T, E, B):
     from baselines_amd import _lib
     spec = hip.PolicySpec(_lib.POLICY_CNN, _lib.DIST_CATEGORICAL, nact, 1, ob_hwc=hwc)
@@ -81,7 +81,10 @@ def test_cnn_policy_grad(hip, hwc, nact, T, E, B):
 
 @pytest.mark.parametrize("cell", ["lstm", "lnlstm"])
 @pytest.mark.parametrize("hwc,nact,T,E,nenv_mb,nlstm", [((36, 36, 2), 4, 6, 6, 3, 32), ((44, 52, 4), 5, 5, 8, 4, 64),
-                                                        ((84, 84, 4), 6, 4, 4, 2, 256)])
+                                                        ((84, 84, 4), 6, 4, 4, 2, 256),
+                                                        # two-step sequences over two env groups, the second part-filled
+                                                        # (whole-sequence launches); one-step sequences (step launches)
+                                                        ((36, 36, 2), 4, 2, 20, 18, 128), ((36, 36, 2), 4, 1, 6, 3, 64)])
 def test_cnn_lstm_policy_grad(hip, hwc, nact, T, E, nenv_mb, nlstm, cell):
     """Env-sequence minibatch (baselines/ppo2/ppo2.py:124-136): whole env rows, masks reset the state;
     plain cell (a2c/utils.py:86-108) and layer-normalised cell (:110-147, gains and biases perturbed
