@@ -9,6 +9,8 @@ without a host round trip per minibatch.
 """
 import time
 
+import os
+
 import numpy as np
 import torch
 
@@ -191,6 +193,7 @@ class Model(object):
             self._sig_dev = [torch.empty(N, dtype=torch.int32, device=self.device) for _ in range(noptepochs)]
             self._idx_free = [None] * noptepochs      # main-stream event: kernels reading _idx_dev[e] done
             self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._side_stats = [None] * noptepochs    # per epoch: (workspace, out) of the advantage statistics taken on the side stream
         return self._pp
 
     def _begin_index_job(self, pp, noptepochs):
@@ -254,18 +257,35 @@ class Model(object):
         ws = self._workspace(nbatch_train)
         stat_ws = self._stats_workspace(nmb)
         row = 0
+        # The advantage statistics of epochs 1.. need the rollout's advantages and that epoch's index list only, so they
+        # are taken on the side stream right behind the list, while the main stream still works through the epoch
+        # before (its kernels leave room on every CU); epoch 0's have nothing to hide behind and stay on the main stream.
+        side_stats = not spec.recurrent and os.environ.get("PPO2HIP_STATS_ON_MAIN") is None
+        if side_stats:
+            advs_ready = torch.cuda.Event()
+            advs_ready.record(main)
         for e in range(noptepochs):
+            stats = None
             if not spec.recurrent:
                 host_idx = pp.wait(e)
                 d_idx = self._idx_dev[e]
                 with torch.cuda.stream(self._copy_stream):
                     if self._idx_free[e] is not None:
-                        self._copy_stream.wait_event(self._idx_free[e])
+                        self._copy_stream.wait_event(self._idx_free[e])      # also frees this epoch's statistics buffers
                     if e == 0:
                         d_idx.copy_(host_idx, non_blocking=True)
                     else:       # this epoch's own permutation arrives; the running order is a device gather
                         self._sig_dev[e].copy_(host_idx, non_blocking=True)
                         hip.compose(self._idx_dev[e - 1], self._sig_dev[e], d_idx)
+                        if side_stats:
+                            if self._side_stats[e] is None or self._side_stats[e][1].shape[0] != nmb:
+                                self._side_stats[e] = (torch.empty(int(_lib.lib.ppo2hip_adv_stats_workspace_bytes(nmb)), dtype=torch.uint8,
+                                                                   device=self.device),
+                                                       torch.empty((nmb, 3), dtype=torch.float64, device=self.device))
+                            if e == 1:
+                                self._copy_stream.wait_event(advs_ready)
+                            stats = hip.adv_stats(ro.advs, d_idx, nbatch_train, nmb, T, E, self._side_stats[e][0],
+                                                  out=self._side_stats[e][1])
                     ev = torch.cuda.Event()
                     ev.record(self._copy_stream)
                 self._set_copied[self._pp_set] = ev
@@ -276,7 +296,8 @@ class Model(object):
                 flat = (envinds[:, None].astype(np.int64) * T + tgrid).astype(np.int32).ravel()   # :134
                 d_idx = torch.from_numpy(flat).to(self.device)
                 d_envs = torch.from_numpy(envinds.copy()).to(self.device)
-            stats = hip.adv_stats(ro.advs, d_idx, nbatch_train, nmb, T, E, stat_ws)
+            if stats is None:
+                stats = hip.adv_stats(ro.advs, d_idx, nbatch_train, nmb, T, E, stat_ws)
             native = comm.native() if comm is not None else None
             if (comm is None or native is not None) and not spec.recurrent and events is None:
                 # the whole epoch (gradient, all-reduce over the ranks, Adam per minibatch) is one library call
