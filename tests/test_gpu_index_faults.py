@@ -75,3 +75,38 @@ def test_compose_reports_a_bad_permutation_entry():
     hip.compose(prev, dev(sigma), out)
     assert hip.take_faults(raise_on_fault=False) == hip.FAULT_COMPOSE_RANGE
     assert hip.take_faults() == 0
+
+
+def test_out_of_range_index_on_image_rollouts_is_reported_not_followed():
+    """nature_cnn: conv1's kernels read the minibatch's frames where they lie in the rollout, through the frame list the
+    gather leaves — a bad index must become frame 0 there, not an address 2^31 frames away."""
+    from baselines_amd import _lib, hip
+    hwc, nact, T, E, B = (84, 84, 4), 6, 2, 8, 16
+    spec = hip.PolicySpec(_lib.POLICY_CNN, _lib.DIST_CATEGORICAL, nact, 1, ob_hwc=hwc)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    theta = torch.randn(spec.nparams, device="cuda", generator=g) * 0.03
+    obs = torch.randint(0, 256, (T, E) + hwc, device="cuda", generator=g, dtype=torch.uint8)
+    f = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    acts = torch.randint(0, nact, (T, E), device="cuda", generator=g, dtype=torch.int32)
+    rref = hip.RolloutRef(spec, obs, acts, f(T, E, 1), f(T, E, 1), f(T, E).abs() + 1.0, f(T, E), T, E)
+    ws = torch.empty(spec.grad_workspace_bytes(B), dtype=torch.uint8, device="cuda")
+    grads, losses = torch.zeros(spec.nparams, device="cuda"), torch.zeros(8, device="cuda")
+    good = np.random.RandomState(1).permutation(T * E)[:B].astype(np.int32)
+
+    def run(idx_host):
+        d_idx = dev(idx_host)
+        stats = hip.adv_stats(rref.keep[5], d_idx, B, 1, T, E)
+        hip.ppo_grad(spec, _lib.LossDesc(0.01, 0.5, 0.5, 1), theta, rref, d_idx, B, stats, 0.1, 1.0 / B, grads, losses, ws)
+
+    assert hip.take_faults() == 0
+    run(good)
+    assert hip.take_faults() == 0
+    for bad_value in (T * E, -1, 2 ** 31 - 1):
+        bad = good.copy()
+        bad[5] = bad_value
+        run(bad)
+        with pytest.raises(_lib.Ppo2HipError, match="out-of-range"):
+            hip.take_faults()
+        assert hip.take_faults() == 0
+        assert torch.isfinite(grads).all()
