@@ -335,9 +335,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Priming, before the warmup the caller asked for: the HIP runtime and the index pipeline settle lazily over the first
-    # dozen updates of a process (one update around the tenth takes 5 ms instead of 1.9 on every box tried; none after
-    # it in runs of 100+ updates).  Untimed, reported as "priming_steps".
+    # Priming, before the warmup the caller asked for.  In a young process a few of the first dozens of hipMemcpyAsync calls
+    # from page-locked memory (the index lists, four per update) hold the calling thread for about 6 ms each — traced to the
+    # runtime call itself, with torch's copy_ and with a bare hipMemcpyAsync alike; none in runs of 100+ updates once the
+    # first dozen updates are past.  One such update in a 20-step timed region is 9 % of it.  Untimed, reported as
+    # "priming_steps".
     priming = int(os.environ.get("PPO2HIP_BENCH_PRIMING", "12"))
     for _ in range(priming):
         step()
