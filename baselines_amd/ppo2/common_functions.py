@@ -229,7 +229,7 @@ class Model(object):
         # Keep at most two updates queued: a host that runs further ahead fills the launch queue, and the
         # launch that then blocks holds the host until the queue has drained, after which the GPU starves.
         inflight = self.__dict__.setdefault("_updates_inflight", [])
-        if len(inflight) >= 2:
+        if len(inflight) >= int(os.environ.get("PPO2HIP_UPDATES_INFLIGHT", "2")):
             inflight.pop(0).synchronize()
         rref = hip.RolloutRef(spec, ro.obs, ro.actions, ro.returns, ro.values, ro.neglogpacs, ro.advs, T, E,
                               ro.dones if spec.recurrent else None, ro.states)

@@ -340,7 +340,9 @@ def main():
     # runtime call itself, with torch's copy_ and with a bare hipMemcpyAsync alike; none in runs of 100+ updates once the
     # first dozen updates are past.  One such update in a 20-step timed region is 9 % of it.  Untimed, reported as
     # "priming_steps".
-    priming = int(os.environ.get("PPO2HIP_BENCH_PRIMING", "12"))
+    # (30 updates of a few ms for the MLP workloads, where a 6 ms stall matters; 4 for the image workloads, whose updates
+    # take 60-140 ms)
+    priming = int(os.environ.get("PPO2HIP_BENCH_PRIMING", "4" if image else "30"))
     for _ in range(priming):
         step()
     for _ in range(args.warmup):
