@@ -32,6 +32,68 @@ class DeviceRollout:
         self.advs = None   # scalar advantage fed to the update: float32 or float64 [T, E]
 
 
+class _IndexUploader:
+    """Moves an index job's lists from the pipeline's page-locked buffers to HBM on a thread and a stream of its own, as
+    the lists are finished, normally an update ahead of their use.  hipMemcpyAsync from page-locked memory now and then
+    holds its calling thread for 3-6 ms (the runtime call itself: torch's copy_ and a bare call alike); on the thread that
+    feeds the GPU that is one update in ten taking 5 ms instead of 1.8.  Here it only delays a copy nobody is waiting for
+    yet.  ``stage[s][e]`` receives epoch e of the job in buffer set s; ``ready`` is the event after its copy, ``free``
+    the event (set by the consumer) after which the staging buffer may be overwritten."""
+
+    def __init__(self, device, pp, n, nepochs):
+        import queue
+        import threading
+        self.device, self.pp = device, pp
+        self.stream = torch.cuda.Stream(device=device)
+        nsets = len(pp.sets)
+        self.stage = [[torch.empty(n, dtype=torch.int32, device=device) for _ in range(nepochs)] for _ in range(nsets)]
+        self.ready = [[None] * nepochs for _ in range(nsets)]
+        self.free = [[None] * nepochs for _ in range(nsets)]
+        self.issued = [[threading.Event() for _ in range(nepochs)] for _ in range(nsets)]
+        self.error = None
+        self._jobs = queue.Queue()
+        self._thread = threading.Thread(target=self._run, name="ppo2hip-index-upload", daemon=True)
+        self._thread.start()
+
+    def submit(self, s, nepochs):
+        for e in range(nepochs):
+            self.issued[s][e].clear()
+        self._jobs.put((s, nepochs))
+
+    def close(self):
+        self._jobs.put(None)
+
+    def _run(self):
+        torch.cuda.set_device(self.device)
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            s, nepochs = job
+            try:
+                for e in range(nepochs):
+                    hip.check(_lib.lib.ppo2hip_perm_wait(self.pp._h, e), "perm_wait")      # blocks without the GIL
+                    with torch.cuda.stream(self.stream):
+                        if self.free[s][e] is not None:
+                            self.stream.wait_event(self.free[s][e])
+                        self.stage[s][e].copy_(self.pp.sets[s][e], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(self.stream)
+                    self.ready[s][e] = ev
+                    self.issued[s][e].set()
+            except BaseException as ex:      # hand the failure to the thread that waits
+                self.error = ex
+                for e in range(nepochs):
+                    self.issued[s][e].set()
+
+    def wait(self, s, e):
+        """(device list, event after its copy) of epoch e of the job in set s; blocks until the copy has been issued."""
+        self.issued[s][e].wait()
+        if self.error is not None:
+            raise self.error
+        return self.stage[s][e], self.ready[s][e]
+
+
 class Model(object):
     """baselines/ppo2/common_functions.py:7-220.
 
@@ -190,7 +252,9 @@ class Model(object):
             self._pp_ahead = False         # a job for the coming update is already running
             self._set_copied = [None, None]   # last copy event out of each buffer set
             self._idx_dev = [torch.empty(N, dtype=torch.int32, device=self.device) for _ in range(noptepochs)]
-            self._sig_dev = [torch.empty(N, dtype=torch.int32, device=self.device) for _ in range(noptepochs)]
+            if getattr(self, "_uploader", None) is not None:
+                self._uploader.close()
+            self._uploader = _IndexUploader(self.device, self._pp, N, noptepochs)
             self._idx_free = [None] * noptepochs      # main-stream event: kernels reading _idx_dev[e] done
             self._copy_stream = torch.cuda.Stream(device=self.device)
             self._side_stats = [None] * noptepochs    # per epoch: (workspace, out) of the advantage statistics taken on the side stream
@@ -205,6 +269,7 @@ class Model(object):
             self._shuffler.adopt_numpy()
         pp.begin(noptepochs, relative=True, buffer_set=s)
         self._pp_set = s
+        self._uploader.submit(s, noptepochs)
 
     def train_on_rollout(self, lr, cliprange, ro, noptepochs, nbatch_train, events=None, more_updates=False):
         """All epochs x minibatches of one update from device-resident rollout buffers.
@@ -267,16 +332,15 @@ class Model(object):
         for e in range(noptepochs):
             stats = None
             if not spec.recurrent:
-                host_idx = pp.wait(e)
-                d_idx = self._idx_dev[e]
+                # this epoch's own permutation of arange(N), uploaded by the side thread (normally long since)
+                sig, sig_ready = self._uploader.wait(self._pp_set, e)
+                d_idx = sig if e == 0 else self._idx_dev[e]
                 with torch.cuda.stream(self._copy_stream):
+                    self._copy_stream.wait_event(sig_ready)
                     if self._idx_free[e] is not None:
                         self._copy_stream.wait_event(self._idx_free[e])      # also frees this epoch's statistics buffers
-                    if e == 0:
-                        d_idx.copy_(host_idx, non_blocking=True)
-                    else:       # this epoch's own permutation arrives; the running order is a device gather
-                        self._sig_dev[e].copy_(host_idx, non_blocking=True)
-                        hip.compose(self._idx_dev[e - 1], self._sig_dev[e], d_idx)
+                    if e > 0:       # the running order is a device gather through the order of the epoch before
+                        hip.compose(d_prev, sig, d_idx)
                         if side_stats:
                             if self._side_stats[e] is None or self._side_stats[e][1].shape[0] != nmb:
                                 self._side_stats[e] = (torch.empty(int(_lib.lib.ppo2hip_adv_stats_workspace_bytes(nmb)), dtype=torch.uint8,
@@ -288,7 +352,8 @@ class Model(object):
                                                   out=self._side_stats[e][1])
                     ev = torch.cuda.Event()
                     ev.record(self._copy_stream)
-                self._set_copied[self._pp_set] = ev
+                d_prev = d_idx
+                self._set_copied[self._pp_set] = sig_ready        # uploads run in order: the last one's event covers the set
                 main.wait_event(ev)
                 d_envs = None
             else:
@@ -312,6 +377,7 @@ class Model(object):
                 done = torch.cuda.Event()
                 done.record(main)
                 self._idx_free[e] = done
+                self._uploader.free[self._pp_set][e] = done
                 continue
             for j in range(nmb):
                 lo = j * nbatch_train
@@ -332,6 +398,7 @@ class Model(object):
                 done = torch.cuda.Event()
                 done.record(main)
                 self._idx_free[e] = done
+                self._uploader.free[self._pp_set][e] = done
         if not spec.recurrent:
             pp.wait_all()
             if not self._own_stream:

@@ -335,14 +335,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Priming, before the warmup the caller asked for.  In a young process a few of the first dozens of hipMemcpyAsync calls
-    # from page-locked memory (the index lists, four per update) hold the calling thread for about 6 ms each — traced to the
-    # runtime call itself, with torch's copy_ and with a bare hipMemcpyAsync alike; none in runs of 100+ updates once the
-    # first dozen updates are past.  One such update in a 20-step timed region is 9 % of it.  Untimed, reported as
-    # "priming_steps".
-    # (30 updates of a few ms for the MLP workloads, where a 6 ms stall matters; 4 for the image workloads, whose updates
-    # take 60-140 ms)
-    priming = int(os.environ.get("PPO2HIP_BENCH_PRIMING", "4" if image else "30"))
+    # Optional extra untimed updates before the caller's warmup (off by default; reported as "priming_steps").
+    priming = int(os.environ.get("PPO2HIP_BENCH_PRIMING", "0"))
     for _ in range(priming):
         step()
     for _ in range(args.warmup):
