@@ -278,8 +278,9 @@ class Model(object):
         every epoch) or :124-136 for recurrent policies (env sequences), drawn from the
         global ``np.random`` stream (or the model's own after ``seed_shuffle``).  The index
         lists are produced by the C++ pipeline while the GPU works on earlier epochs and
-        reach HBM on a side stream (each epoch's permutation of arange(N) is uploaded and chained
-        onto the previous order by a device gather).  Nothing here waits for the GPU: the result is a device
+        reach HBM through an uploader thread with a stream of its own (each epoch's permutation of
+        arange(N) is copied into a staging buffer as soon as it is finished and chained onto the
+        previous order by a device gather on the side stream).  Nothing here waits for the GPU: the result is a device
         tensor holding the mean of the per-minibatch loss rows (:139).  ``events``: optional list
         that receives a (start, end) pair of timing events around every gradient evaluation.
         ``more_updates``: another update of the same shape follows; when the model owns its
