@@ -141,8 +141,9 @@ struct AdamFuse {
     float *theta, *m, *v;
     float a, beta1, beta2, omb1, omb2, eps, gscale, max_norm;
     float *header;            // adam scratch header: [0] global norm, [1] applied scale
-    double *partial;          // [blocks] per-block sums of squares          (workspace of the fused gradient kernel)
-    unsigned *barrier;        // [2] arrival counter (zeroed by the gradient kernel of the same minibatch), fault flag
+    unsigned long long *words; // [2 x blocks] per-block sums of squares as tagged halves (workspace of the fused gradient kernel)
+    unsigned *fault;          // the device's fault word: a block that gives up waiting raises kFaultGridSync there
+    unsigned tag;             // this launch's tag (never zero, never the tag of the launch before on the same workspace)
 };
 size_t fused_adam_extra_bytes();
 // slabs: nslabs_policy gradient images of the policy trunk, then nslabs_value of the value trunk

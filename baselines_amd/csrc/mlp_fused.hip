@@ -18,6 +18,8 @@
 //   * weight gradients accumulate in registers across all of a wave's tiles, are summed over
 //     the workgroup's four waves in LDS and leave as one slab per workgroup; a fixed-order
 //     reduction over slabs follows (no float atomics: run-to-run reproducible).
+#include <atomic>
+
 #include "gemm_core.hpp"
 #include "kernels.hpp"
 
@@ -540,15 +542,25 @@ struct FinalizeArgs {
 };
 
 constexpr int kFusedAdamMaxBlocks = 256;      // one per CU: resident together whatever else the chip is doing
-size_t fused_adam_extra_bytes() { return 256 + kFusedAdamMaxBlocks * sizeof(double); }
+size_t fused_adam_extra_bytes() { return kFusedAdamMaxBlocks * 2 * sizeof(unsigned long long); }
 
 constexpr int kFinGroups = 16;   // slab groups per block: 1024 threads, every lane a handful of independent loads
 
 // ADAM: the blocks that sum gradient elements then take the optimiser step on those same elements.  The global norm
-// needs every block's sum of squares: each stores its own with an agent-scope store, arrives on a counter and waits
-// until all have (all blocks of this launch are resident at once: at most 2 x 1024 threads of them per CU are asked
-// for, far fewer than the chip holds); the wait is bounded, and a block that gives up raises the fault flag instead of
-// spinning on.  The parameters, m and v of a block's elements are loaded before the wait.
+// needs every block's sum of squares, and the hand-over is one hop: a block publishes its sum as two 64-bit words
+// {launch tag, half of the double}, written with agent-scope stores, and every block reads all the words with
+// agent-scope loads until each carries this launch's tag - no arrival counter, no wait for the store to drain, no
+// cache write-back or invalidate.  All blocks of the launch are resident at once (at most 2 x 1024 threads of them per
+// CU are asked for, far fewer than the chip holds); the wait is bounded, and a lane that gives up raises the fault
+// word's grid-sync bit instead of spinning on.  The parameters, m and v of a block's elements are loaded before the
+// wait.  Tags come from a process-wide counter, so what an earlier launch left in the words never matches.
+static unsigned next_adam_tag() {
+    static std::atomic<unsigned> counter{0};
+    unsigned t = counter.fetch_add(1, std::memory_order_relaxed) + 1;
+    if (t == 0) t = counter.fetch_add(1, std::memory_order_relaxed) + 1;
+    return t;
+}
+
 template <bool ADAM>
 __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(FinalizeArgs f, AdamFuse ad) {
     __shared__ float part[kFinGroups][64];
@@ -631,25 +643,39 @@ __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(Finaliz
                 const double x = (double)(t * ad.gscale);
                 const double mine = wave_sum(x * x);
                 if (lane == 0) {
-                    // the sum goes out as a write-through (agent-scope) store and is drained before the arrival is counted;
-                    // the poll and the reads of the other blocks' sums below are agent-scope loads: no cache write-back or
-                    // invalidate is needed on either side
-                    __hip_atomic_store(&ad.partial[b], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_fetch_add(&ad.barrier[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    int spins = 0;
-                    while (__hip_atomic_load(&ad.barrier[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nb) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1 << 22)) {      // never expected; leave rather than hang the device
-                            __hip_atomic_store(&ad.barrier[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(mine), tg = (unsigned long long)ad.tag << 32;
+                    __hip_atomic_store(&ad.words[2 * b], tg | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&ad.words[2 * b + 1], tg | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // every block sums the same values in the same order, so all of them apply the same scale
+                // a lane's words (blocks lane, lane + 64, ...) are requested together, so a round of polling is one round trip
+                constexpr int kMine = kFusedAdamMaxBlocks / 64;
+                unsigned long long hi[kMine], lo[kMine];
+                int spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < kMine; u++) {
+                        const int q = lane + 64 * u;
+                        hi[u] = lo[u] = (unsigned long long)ad.tag << 32;
+                        if (q < nb) {
+                            hi[u] = __hip_atomic_load(&ad.words[2 * q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            lo[u] = __hip_atomic_load(&ad.words[2 * q + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
+#pragma unroll
+                    for (int u = 0; u < kMine; u++) ok = ok && (unsigned)(hi[u] >> 32) == ad.tag && (unsigned)(lo[u] >> 32) == ad.tag;
+                    if (ok) break;
+                    if (++spins > (1 << 20)) {      // never expected; leave rather than hang the device
+                        atomicOr(ad.fault, kFaultGridSync);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                __builtin_amdgcn_wave_barrier();
-                // every block sums the same values in the same order, so all of them apply the same scale
                 double ss = 0.0;
-                for (int q = lane; q < nb; q += 64) ss += __hip_atomic_load(&ad.partial[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int u = 0; u < kMine; u++)
+                    if (lane + 64 * u < nb) ss += __longlong_as_double((long long)((hi[u] << 32) | (lo[u] & 0xffffffffull)));
                 ss = wave_sum(ss);
                 const float norm = (float)sqrt(ss);
                 scale = ad.gscale * (ad.max_norm / fmaxf(norm, ad.max_norm));
@@ -711,7 +737,11 @@ int fused_finalize(const FusedImage &im, const float *slabs, int nslabs_policy, 
             set_error("fused_finalize: optimiser step cannot be folded in for this shape");
             return PPO2HIP_EUNSUPPORTED;
         }
-        hipLaunchKernelGGL(fused_finalize_kernel<true>, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(64 * kFinGroups), 0, s, fa, *adam);
+        AdamFuse af = *adam;
+        af.tag = next_adam_tag();
+        af.fault = fault_word();
+        if (!af.fault) return PPO2HIP_EINVAL;
+        hipLaunchKernelGGL(fused_finalize_kernel<true>, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(64 * kFinGroups), 0, s, fa, af);
     } else {
         hipLaunchKernelGGL(fused_finalize_kernel<false>, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(64 * kFinGroups), 0, s, fa, AdamFuse{});
     }

@@ -89,7 +89,6 @@ struct Fused16Args {
     unsigned div_magic;      // smp / T = (t + ((smp - t) >> div_sh1)) >> div_sh2 with t = mulhi(div_magic, smp)
     int div_sh1, div_sh2;
     int nwg_policy;          // workgroups 0 .. nwg_policy-1 run the policy trunk, the rest the value trunk
-    unsigned *fin_barrier;   // arrival counter and fault flag of the finalize launch that follows: zeroed here
     float *slabs;            // [workgroup][SLAB]: the policy trunk's images, then the value trunk's
     double *loss_partial;    // [gridDim.x][kLossStride]
 };
@@ -129,7 +128,6 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    if (blockIdx.x == 0 && threadIdx.x < 2) g.fin_barrier[threadIdx.x] = 0u;
     const bool is_value = (int)blockIdx.x >= g.nwg_policy;
     const int nwg_trunk = is_value ? (int)gridDim.x - g.nwg_policy : g.nwg_policy;
     const int wg_in_trunk = is_value ? (int)blockIdx.x - g.nwg_policy : (int)blockIdx.x;
@@ -824,12 +822,8 @@ int mlp_fused16_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, 
     float *slabs = (float *)ws;
     double *lpart = (double *)((char *)ws + align_up((size_t)grid * SLAB * sizeof(float), 256));
     char *extra = (char *)lpart + align_up((size_t)grid * kLossStride * sizeof(double), 256);
-    if (adam) {
-        adam->barrier = (unsigned *)extra;
-        adam->partial = (double *)(extra + 256);
-    }
+    if (adam) adam->words = (unsigned long long *)extra;
     Fused16Args g;
-    g.fin_barrier = (unsigned *)extra;
     g.obs = (const float *)ro.obs; g.actions = ro.actions; g.returns = ro.returns; g.values = ro.values;
     g.neglogpacs = ro.neglogpacs; g.advs = ro.advs; g.adv_f64 = ro.adv_f64; g.T = ro.T; g.E = ro.E; g.n = ro.n;
     { const int64_t ns = rollout_samples(ro); g.nsamples = (unsigned)(ns < 0x7fffffffll ? ns : 0x7fffffffll); }
