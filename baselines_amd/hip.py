@@ -404,8 +404,9 @@ def take_faults(raise_on_fault=True):
     check(lib.ppo2hip_take_faults(ctypes.byref(bits), _stream()), "take_faults")
     if bits.value and raise_on_fault:
         if bits.value & FAULT_GRID_SYNC:
-            raise _lib.Ppo2HipError("a whole-sequence LSTM launch gave up waiting for its peer workgroups (is the GPU shared with "
-                                    "another job?); results since the last check are invalid — PPO2HIP_LSTM_SEQ_OFF=1 takes one launch per step")
+            raise _lib.Ppo2HipError("a launch whose workgroups hand values to each other (whole-sequence LSTM, or the optimiser step folded "
+                                    "into the epoch call) gave up waiting for its peers (is the GPU shared with another job?); results since "
+                                    "the last check are invalid — PPO2HIP_LSTM_SEQ_OFF=1 takes one LSTM launch per step")
         what = [name for bit, name in ((FAULT_INDEX_RANGE, "a minibatch index list"), (FAULT_COMPOSE_RANGE, "a permutation handed to compose"))
                 if bits.value & bit]
         raise _lib.Ppo2HipError("index check failed (code %d): out-of-range entry in %s; results since the last check are invalid" % (_lib.EINVAL, " and ".join(what)))

@@ -192,7 +192,8 @@ int ppo2hip_compose_i32(const int32_t *prev, const int32_t *sigma, int32_t *out,
  * meaningless; the Python layer raises Ppo2HipError(EINVAL) when it collects a non-zero word with the losses. */
 #define PPO2HIP_FAULT_INDEX_RANGE 1u
 #define PPO2HIP_FAULT_COMPOSE_RANGE 2u
-#define PPO2HIP_FAULT_GRID_SYNC 4u      /* a whole-sequence LSTM launch gave up waiting for its peer workgroups */
+#define PPO2HIP_FAULT_GRID_SYNC 4u      /* a launch whose workgroups hand values to each other (whole-sequence LSTM, the
+                                         * optimiser step folded into ppo2hip_ppo_epoch) gave up waiting for its peers */
 int ppo2hip_take_faults(uint32_t *bits, void *stream);
 
 /* ------------------------------------------------------------------------
