@@ -19,6 +19,7 @@
 //     the workgroup's four waves in LDS and leave as one slab per workgroup; a fixed-order
 //     reduction over slabs follows (no float atomics: run-to-run reproducible).
 #include <atomic>
+#include <chrono>
 
 #include "gemm_core.hpp"
 #include "kernels.hpp"
@@ -554,10 +555,13 @@ constexpr int kFinGroups = 16;   // slab groups per block: 1024 threads, every l
 // CU are asked for, far fewer than the chip holds); the wait is bounded, and a lane that gives up raises the fault
 // word's grid-sync bit instead of spinning on.  The parameters, m and v of a block's elements are loaded before the
 // wait.  Tags come from a process-wide counter, so what an earlier launch left in the words never matches.
+// (the sequence starts at a clock-derived value and advances by an odd constant: consecutive launches differ in many bits,
+// 2^32 launches pass before a tag returns, and whatever a fresh workspace holds - zeros, small integers, float bit
+// patterns - matches a tag only with the probability of a 32-bit collision)
 static unsigned next_adam_tag() {
-    static std::atomic<unsigned> counter{0};
-    unsigned t = counter.fetch_add(1, std::memory_order_relaxed) + 1;
-    if (t == 0) t = counter.fetch_add(1, std::memory_order_relaxed) + 1;
+    static std::atomic<unsigned> counter{(unsigned)std::chrono::steady_clock::now().time_since_epoch().count() * 2654435761u};
+    unsigned t = counter.fetch_add(0x9e3779b9u, std::memory_order_relaxed);
+    if (t == 0) t = counter.fetch_add(0x9e3779b9u, std::memory_order_relaxed);
     return t;
 }
 
