@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwd a) {
     }
     const int el = tid >> 4, ul = tid & 15, e = e0 + el, j = u0 + ul;
     const bool live = e < a.nenv;
-    const int ee = live ? e : 0;
+    const int ee = live ? e : a.nenv - 1;          // rows past the last env re-read that env's inputs (same env group) and store nothing
     float dcm = 0.f;
     bool gave_up = false;
     for (int t = a.T - 1; t >= 0; t--) {
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwd a) {
         const float cv = a.c[sr], cmv = a.cm[sr], dhh = a.dh_head[sr];
         const float keep = (!last && a.masks[(int64_t)ee * a.T + t + 1]) ? 0.f : 1.f;
         float dhm = 0.f;
-        if (!last) {
+        if (!last && live) {          // a row past the last env publishes zeros and needs no sum: it never waits
             unsigned long long *xp = a.xchg + (((int64_t)(t & 1) * NUB) * a.nenv + ee) * NH + j;
             const unsigned want = a.tag0 + (unsigned)t;
             unsigned long long w[NUB];

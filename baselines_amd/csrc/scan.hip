@@ -55,12 +55,104 @@ __global__ void gae_kernel(const float *__restrict__ rewards, const float *__res
             last = __dadd_rn(delta, __dmul_rn(__dmul_rn(gl, nnt), last));
             const float a = (float)last;
             const float ret = __fadd_rn(a, vl[u]);
-            advs[off] = a;
+            if (advs) advs[off] = a;
             returns[off] = ret;
             if (advs_ori) advs_ori[off] = __fsub_rn(ret, vl[u]);
             nextvalue = v;
             nnt = 1.0 - (double)(dn[u] != 0);   // dones[t] masks the step from t-1 to t
         }
+    }
+}
+
+// The bandwidth regime (64 K columns and more): a lane owns TWO adjacent columns — 8-byte loads and stores, a quarter
+// of the chip's wave slots still filled at 65536 columns — and keeps two batches of kGaeVecU steps in flight: the loads
+// of batch k + 1 are issued before batch k's arithmetic, so a wave always has 16-32 steps (3 loads each) under way.
+// The rollout is read once and written once, so every access is marked non-temporal.  Same operations in the same
+// order as gae_kernel for each column: the bits are the same.
+// R1: one value channel — the two columns are two envs and their done flags one 16-bit load.
+typedef float gae_f32x2 __attribute__((ext_vector_type(2)));
+constexpr int kGaeVecU = 16, kGaeVecBlock = 64;
+
+template <bool R1>
+__global__ __launch_bounds__(kGaeVecBlock) void gae_vec2_kernel(
+    const float *__restrict__ rewards, const float *__restrict__ values, const uint8_t *__restrict__ dones,
+    const float *__restrict__ last_values, const uint8_t *__restrict__ last_dones, GammaVec gv, double lam, int T, int E,
+    int R, float *__restrict__ advs, float *__restrict__ returns, float *__restrict__ advs_ori) {
+    constexpr int U = kGaeVecU;
+    using F = gae_f32x2;
+    const int64_t CV = (int64_t)E * R / 2;                  // column pairs per row
+    const int64_t cv = (int64_t)blockIdx.x * kGaeVecBlock + threadIdx.x;
+    if (cv >= CV) return;
+    const F *rw_p = (const F *)rewards + cv;
+    const F *vl_p = (const F *)values + cv;
+    F *ad_p = advs ? (F *)advs + cv : nullptr;
+    F *rt_p = (F *)returns + cv;
+    F *ao_p = advs_ori ? (F *)advs_ori + cv : nullptr;
+    int env[2];
+    double gamma[2], gl[2], nextvalue[2], nnt[2], last[2];
+    {
+        const F lv = ((const F *)last_values)[cv];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int64_t c = 2 * cv + i;
+            env[i] = (int)(c / R);
+            gamma[i] = gv.g[R1 ? 0 : (int)(c - (int64_t)env[i] * R)];
+            gl[i] = __dmul_rn(gamma[i], lam);
+            nextvalue[i] = (double)lv[i];
+            nnt[i] = 1.0 - (double)(last_dones[env[i]] != 0);
+            last[i] = 0.0;
+        }
+    }
+    F rwA[U], vlA[U], rwB[U], vlB[U];
+    uint32_t dnA[U], dnB[U];               // the pair's two done flags: bits 0-7 and 8-15
+    auto fetch = [&](int t, F (&rw)[U], F (&vl)[U], uint32_t (&dn)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int tt = t - u >= 0 ? t - u : 0;       // a last batch that runs past step 0 repeats step 0's loads, unused
+            const int64_t off = (int64_t)tt * CV;
+            rw[u] = __builtin_nontemporal_load(rw_p + off);
+            vl[u] = __builtin_nontemporal_load(vl_p + off);
+            if constexpr (R1) {
+                dn[u] = __builtin_nontemporal_load((const uint16_t *)dones + off + cv);
+            } else {
+                const uint8_t *dr = dones + (int64_t)tt * E;
+                dn[u] = (uint32_t)dr[env[0]] | ((uint32_t)dr[env[1]] << 8);
+            }
+        }
+    };
+    auto compute = [&](int t, F (&rw)[U], F (&vl)[U], uint32_t (&dn)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (t - u < 0) break;
+            const int64_t off = (int64_t)(t - u) * CV;
+            F a2, r2, o2;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const float vf = vl[u][i];
+                const double v = (double)vf;
+                double delta = __dadd_rn((double)rw[u][i], __dmul_rn(__dmul_rn(gamma[i], nextvalue[i]), nnt[i]));
+                delta = __dsub_rn(delta, v);
+                last[i] = __dadd_rn(delta, __dmul_rn(__dmul_rn(gl[i], nnt[i]), last[i]));
+                const float a = (float)last[i];
+                const float ret = __fadd_rn(a, vf);
+                a2[i] = a;
+                r2[i] = ret;
+                o2[i] = __fsub_rn(ret, vf);
+                nextvalue[i] = v;
+                nnt[i] = 1.0 - (double)(((dn[u] >> (8 * i)) & 0xffu) != 0);   // dones[t] masks the step from t-1 to t
+            }
+            if (ad_p) __builtin_nontemporal_store(a2, ad_p + off);
+            __builtin_nontemporal_store(r2, rt_p + off);
+            if (ao_p) __builtin_nontemporal_store(o2, ao_p + off);
+        }
+    };
+    fetch(T - 1, rwA, vlA, dnA);
+    for (int t = T - 1; t >= 0; t -= 2 * U) {
+        if (t - U >= 0) fetch(t - U, rwB, vlB, dnB);
+        compute(t, rwA, vlA, dnA);
+        if (t - U < 0) break;
+        if (t - 2 * U >= 0) fetch(t - 2 * U, rwA, vlA, dnA);
+        compute(t - U, rwB, vlB, dnB);
     }
 }
 
@@ -171,7 +263,7 @@ __global__ __launch_bounds__(kGaeThreads) void gae_tiled_kernel(
                 const int64_t off = (int64_t)(t0 - tt) * C + c0 + j;
                 const float a = (float)s_delta[e];
                 const float ret = __fadd_rn(a, vkeep[i]);
-                advs[off] = a;
+                if (advs) advs[off] = a;
                 returns[off] = ret;
                 if (advs_ori) advs_ori[off] = __fsub_rn(ret, vkeep[i]);
             }
@@ -291,21 +383,31 @@ extern "C" int ppo2hip_gae_f32(const float *rewards, const float *values, const 
                                float *returns, float *advs_ori, void *stream) {
     PPO2HIP_REQUIRE(T >= 0 && E >= 0 && R >= 1 && R <= kMaxR, "gae: bad shape T=%d E=%d R=%d (R <= %d)", T, E, R, kMaxR);
     if (T == 0 || E == 0) return PPO2HIP_OK;
-    PPO2HIP_REQUIRE(rewards && values && dones && last_values && last_dones && gamma && advs && returns,
-                    "gae: null pointer");
+    PPO2HIP_REQUIRE(rewards && values && dones && last_values && last_dones && gamma && returns, "gae: null pointer");
     GammaVec gv;
     for (int i = 0; i < kMaxR; i++) gv.g[i] = i < R ? gamma[i] : 0.0;
     const int64_t C = (int64_t)E * R;
-    const int block = C <= 65536 ? 64 : 256;   // few columns: spread them over more CUs
-    const int64_t grid = ceil_div(C, block);
-    // one lane per column fills the chip from about 64 K columns on; below that, blocks that stream chunks
-    // through LDS keep far more loads in flight per column
-    if (C < 65536 && T >= 32)
-        hipLaunchKernelGGL(gae_tiled_kernel, dim3((unsigned)ceil_div(C, kGaeCols)), dim3(kGaeThreads), 0, (hipStream_t)stream,
+    hipStream_t s = (hipStream_t)stream;
+    auto aligned = [](const void *p, uintptr_t a) { return ((uintptr_t)p & (a - 1)) == 0; };
+    // one lane per column (or column pair) fills the chip from about 64 K columns on; below that, blocks that stream
+    // chunks through LDS keep far more loads in flight per column
+    if (C < 65536 && T >= 32) {
+        hipLaunchKernelGGL(gae_tiled_kernel, dim3((unsigned)ceil_div(C, kGaeCols)), dim3(kGaeThreads), 0, s,
                            rewards, values, dones, last_values, last_dones, gv, lam, T, E, R, advs, returns, advs_ori);
-    else
-        hipLaunchKernelGGL(gae_kernel<8>, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)stream, rewards,
-                           values, dones, last_values, last_dones, gv, lam, T, E, R, advs, returns, advs_ori);
+    } else if (C >= 65536 && C % 2 == 0 && aligned(rewards, 8) && aligned(values, 8) && aligned(last_values, 8) &&
+               aligned(advs, 8) && aligned(returns, 8) && aligned(advs_ori, 8) && (R > 1 || aligned(dones, 2))) {
+        const dim3 grid((unsigned)ceil_div(C / 2, kGaeVecBlock));
+        if (R == 1)
+            hipLaunchKernelGGL(gae_vec2_kernel<true>, grid, dim3(kGaeVecBlock), 0, s, rewards, values, dones, last_values,
+                               last_dones, gv, lam, T, E, R, advs, returns, advs_ori);
+        else
+            hipLaunchKernelGGL(gae_vec2_kernel<false>, grid, dim3(kGaeVecBlock), 0, s, rewards, values, dones, last_values,
+                               last_dones, gv, lam, T, E, R, advs, returns, advs_ori);
+    } else {
+        const int block = C <= 65536 ? 64 : 256;   // few columns: spread them over more CUs
+        hipLaunchKernelGGL(gae_kernel<16>, dim3((unsigned)ceil_div(C, block)), dim3(block), 0, s, rewards, values, dones,
+                           last_values, last_dones, gv, lam, T, E, R, advs, returns, advs_ori);
+    }
     return check_launch("gae_kernel");
 }
 

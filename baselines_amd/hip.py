@@ -39,8 +39,10 @@ def _as_u8(t):
 # scans
 # --------------------------------------------------------------------------------------
 
-def gae(rewards, values, dones, last_values, last_dones, gamma, lam, want_advs_ori=True):
-    """GAE over a time-major rollout ([T,E,R] float32); returns (advs, returns, advs_ori)."""
+def gae(rewards, values, dones, last_values, last_dones, gamma, lam, want_advs_ori=True, want_advs=True):
+    """GAE over a time-major rollout ([T,E,R] float32); returns (advs, returns, advs_ori).  ``want_advs=False`` skips the
+    scan's own advantage array (None in its place): Runner.run hands on returns only
+    (baselines/ppo2/common_functions.py:344) and the driver recomputes ``returns - values`` (advs_ori)."""
     rewards = _dev(rewards, torch.float32, "rewards")
     values = _dev(values, torch.float32, "values")
     if rewards.dim() != 3 or values.shape != rewards.shape:
@@ -52,7 +54,7 @@ def gae(rewards, values, dones, last_values, last_dones, gamma, lam, want_advs_o
     if tuple(dones.shape) != (T, E) or last_dones.numel() != E or last_values.numel() != E * R:
         raise ValueError("dones [T,E], last_dones [E], last_values [E,R] expected")
     g = np.ascontiguousarray(np.broadcast_to(np.asarray(gamma, np.float64), (R,)))
-    advs = torch.empty_like(rewards)
+    advs = torch.empty_like(rewards) if want_advs else None
     rets = torch.empty_like(rewards)
     ori = torch.empty_like(rewards) if want_advs_ori else None
     check(lib.ppo2hip_gae_f32(_ptr(rewards), _ptr(values), _ptr(dones), _ptr(last_values), _ptr(last_dones),

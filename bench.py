@@ -310,6 +310,23 @@ def main():
                   nbatch_act=E, nbatch_train=B, nsteps=T, ent_coef=cfg["ent_coef"], vf_coef=0.5, max_grad_norm=0.5,
                   upstream_loss=cfg["upstream"], comm=comm)
     model.seed_shuffle(0)                 # same index stream on every rank
+    comm_info = None
+    if world > 1:
+        # Proof that the collective the timed region uses spans every rank: each rank contributes {its id, 1} to a SUM
+        # all-reduce through the same communicator object (the library's own RCCL communicator when the transport is
+        # "rccl": ppo2hip_allreduce_f64) and must get {N(N-1)/2, N} back.
+        probe = torch.tensor([float(rank), 1.0], dtype=torch.float64, device=device)
+        comm.allreduce_sum_(probe)
+        id_sum, ranks_seen = (int(round(x)) for x in probe.cpu().tolist())
+        if ranks_seen != world or id_sum != world * (world - 1) // 2:
+            raise SystemExit("rank %d: the all-reduce reached %d ranks (id sum %d), expected %d (%d)"
+                             % (rank, ranks_seen, id_sum, world, world * (world - 1) // 2))
+        native = comm.native()
+        comm_info = {"transport": comm.transport, "mode": comm.mode, "ranks_seen": ranks_seen, "rank_id_sum": id_sum,
+                     "library_communicator": native is not None,
+                     "library_comm_size": native.size if native is not None else None,
+                     "epoch_call": "ppo_epoch_dp" if (native is not None and not cfg.get("nlstm")) else "ppo_grad + allreduce + adam_step per minibatch",
+                     "allreduce_bytes_per_minibatch": 4 * model.spec.nparams}
     ro = (make_image_rollout if image else make_rollout)(model, cfg, seed=rank, device=device)
     gamma = 0.99 if R == 1 else [0.99] * R
 
@@ -317,8 +334,10 @@ def main():
         if events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        # the scan's own advantage array is left out: the update consumes returns and `returns - values` only, as the
+        # reference's Runner.run hands on mb_returns but not mb_advs (baselines/ppo2/common_functions.py:344, ppo2.py:92)
         ro.advs_gae, ro.returns, ro.advs_ori = hip.gae(ro.rewards, ro.values, ro.dones, ro.last_values, ro.last_dones,
-                                                       gamma, 0.95)
+                                                       gamma, 0.95, want_advs=False)
         if events is not None:
             e1.record()
             events["gae"].append((e0, e1))
@@ -371,14 +390,14 @@ def main():
     import ctypes
     from baselines_amd._lib import lib, check
     gv = (ctypes.c_double * R)(*([0.99] * R))
-    outs = [torch.empty_like(ro.rewards) for _ in range(3)]
+    outs = [None] + [torch.empty_like(ro.rewards) for _ in range(2)]      # returns and returns - values, as in step()
     dones_u8, last_dones_u8 = ro.dones.to(torch.uint8), ro.last_dones.to(torch.uint8)
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def gae_raw():
         check(lib.ppo2hip_gae_f32(ptr(ro.rewards), ptr(ro.values), ptr(dones_u8), ptr(ro.last_values), ptr(last_dones_u8), gv,
-                                  0.95, T, E, R, ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), stream), "gae")
+                                  0.95, T, E, R, None, ptr(outs[1]), ptr(outs[2]), stream), "gae")
 
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 20
@@ -390,7 +409,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     gae_ms = e0.elapsed_time(e1) / reps
-    assert torch.equal(outs[0], ro.advs_gae) and torch.equal(outs[1], ro.returns)
+    assert torch.equal(outs[1], ro.returns) and torch.equal(outs[2], ro.advs_ori)
 
     # the same kernel family on a rollout large enough to be bandwidth- rather than latency-bound: the 65536-env x
     # 128-step rollout of the env-sharded configuration, whole, on this one GPU (R = 1)
@@ -399,7 +418,7 @@ def main():
         gen = torch.Generator(device=device)
         gen.manual_seed(3)
         g1 = (ctypes.c_double * 1)(0.99)
-        # four distinct sets of inputs and outputs (176 MB each, 704 MB in all) visited in turn, so that no launch finds
+        # four distinct sets of inputs and outputs (143 MB each, 570 MB in all) visited in turn, so that no launch finds
         # its operands in the 256 MB Infinity Cache left there by the launch before it
         sets = []
         for _ in range(nsets):
@@ -408,12 +427,12 @@ def main():
             dn = (torch.rand(Tl, El, generator=gen, device=device) < 0.005).to(torch.uint8)
             lv = torch.randn(El, 1, generator=gen, device=device)
             ld = torch.zeros(El, dtype=torch.uint8, device=device)
-            sets.append((rw, vl, dn, lv, ld, [torch.empty_like(rw) for _ in range(3)]))
+            sets.append((rw, vl, dn, lv, ld, [torch.empty_like(rw) for _ in range(2)]))
 
         def call(k):
             rw, vl, dn, lv, ld, o = sets[k % nsets]
-            check(lib.ppo2hip_gae_f32(ptr(rw), ptr(vl), ptr(dn), ptr(lv), ptr(ld), g1, 0.95, Tl, El, 1, ptr(o[0]), ptr(o[1]),
-                                      ptr(o[2]), stream), "gae")
+            check(lib.ppo2hip_gae_f32(ptr(rw), ptr(vl), ptr(dn), ptr(lv), ptr(ld), g1, 0.95, Tl, El, 1, None, ptr(o[0]),
+                                      ptr(o[1]), stream), "gae")
         for k in range(nsets):
             call(k)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -424,12 +443,12 @@ def main():
         b.record()
         torch.cuda.synchronize()
         ms = a.elapsed_time(b) / reps
-        nbytes = Tl * El * 21 + El * 5           # 17 B/sample of the scan itself + the third output (advs_ori, 4 B/sample)
-        return {"bound": "hbm", "kernel": "gae_kernel<8>", "workload": "65536 envs x 128 steps, R=1 (configs[3], whole, on one GPU)",
+        nbytes = Tl * El * 17 + El * 5           # rewards 4 + values 4 + done 1 read, two float32 outputs written
+        return {"bound": "hbm", "kernel": "gae_vec2_kernel<true>", "workload": "65536 envs x 128 steps, R=1 (configs[3], whole, on one GPU)",
                 "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": nbytes, "ms_per_launch": ms,
-                "buffer_sets": nsets, "note": "bytes include the third output array; %d buffer sets of 176 MB rotate so the "
-                                              "256 MB Infinity Cache holds none of a launch's operands" % nsets}
+                "buffer_sets": nsets, "note": "outputs: returns and returns - values (what the update reads); %d buffer sets of "
+                                              "143 MB rotate so the 256 MB Infinity Cache holds none of a launch's operands" % nsets}
     gae_large_roofline = gae_large() if rank == 0 else None
     # median over the minibatches: the first evaluation of an epoch can sit behind the index upload, which is not
     # launch time
@@ -506,6 +525,8 @@ def main():
                                 "note": "1 GiB device-to-device copy (read + write) and an 8192^3 fp32 torch.matmul on this card"},
             "losses": [float(x) for x in losses],
         }
+        if comm_info is not None:
+            out["comm"] = comm_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, ro, cfg)
         print(json.dumps(out))

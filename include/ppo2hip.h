@@ -43,7 +43,8 @@ const char *ppo2hip_last_error(void);
  *   rewards, values : float32 [T, E, R]     dones : uint8 [T, E] (done BEFORE step t, :258)
  *   last_values     : float32 [E, R] (:304) last_dones : uint8 [E] (:319)
  *   gamma           : HOST double[R] (self.gamma, :232), R <= 8      lam : scalar
- *   advs, returns   : float32 [T, E, R] out (mb_advs :327, mb_returns :328)
+ *   returns         : float32 [T, E, R] out (mb_returns :328)
+ *   advs            : float32 [T, E, R] out or NULL (mb_advs :327 — Runner.run does not return it, :344)
  *   advs_ori        : float32 [T, E, R] out or NULL — `returns - values` as the driver
  *                     recomputes it in float32, baselines/ppo2/ppo2.py:92
  * float64 carry, float32 store, returns = advs + values in float32. */

@@ -46,4 +46,8 @@ def test_bench_two_ranks_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "dp2" in d["config"]["parallelism"]
     assert "cpu_baseline" not in d                       # rank 0 at N = 1 only
+    # the collective that the timed region uses reached both ranks: SUM of {rank id, 1} came back as {1, 2}
+    c = d["comm"]
+    assert c["ranks_seen"] == 2 and c["rank_id_sum"] == 1 and c["transport"] == "host" and c["mode"] == "mpi"
+    assert c["library_communicator"] is False           # two ranks share this box's one GPU: RCCL cannot run here
     assert abs(d["value"] - 2 * 524288 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6

@@ -60,6 +60,39 @@ def test_gae_full_size_and_env_shards(mods, T, E, shards):
     np.testing.assert_array_equal(a1.cpu().numpy(), (rewards.astype(np.float64) - values.astype(np.float64)).astype(np.float32))
 
 
+# 64 K columns and more take the column-pair kernel (two batches of 16 steps in flight) when the column count is even and
+# the arrays are 8-byte aligned, the one-lane-per-column kernel otherwise: R = 1 and R = 5 (a pair may straddle two envs),
+# step counts that end in a part-filled batch or fit inside one, an odd column count, an odd-offset done array, and the
+# scan's own advantage array left out (Runner.run does not return it, baselines/ppo2/common_functions.py:344)
+@pytest.mark.parametrize("T,E,R,case", [(40, 65536, 1, "pair"), (7, 70000, 1, "pair"), (33, 16384, 5, "pair"), (16, 13108, 5, "pair"),
+                                        (19, 65537, 1, "odd columns"), (21, 65536, 1, "odd done offset"), (32, 13109, 5, "odd columns")])
+def test_gae_wide_rollout_routes(mods, T, E, R, case):
+    hip = mods["hip"]
+    rng = np.random.RandomState(T * 7 + E + R)
+    rewards = rng.randn(T, E, R).astype(np.float32)
+    values = rng.randn(T, E, R).astype(np.float32)
+    dones = rng.rand(T, E) < 0.05
+    last_values = rng.randn(E, R).astype(np.float32)
+    last_dones = rng.rand(E) < 0.05
+    gamma = 0.99 if R == 1 else [0.99, 0.97, 0.97, 0.95, 0.95]
+    d_dones = dev(dones)
+    if case == "odd done offset":
+        buf = torch.zeros(T * E + 1, dtype=torch.bool, device="cuda")
+        d_dones = buf[1:].view(T, E)
+        d_dones.copy_(dev(dones))
+        assert d_dones.data_ptr() % 2 == 1
+    o_advs, o_rets = scan.gae(rewards, values, dones, last_values, last_dones, gamma, 0.95)
+    advs, rets, ori = hip.gae(dev(rewards), dev(values), d_dones, dev(last_values), dev(last_dones), gamma, 0.95)
+    np.testing.assert_array_equal(advs.cpu().numpy(), o_advs)
+    np.testing.assert_array_equal(rets.cpu().numpy(), o_rets)
+    np.testing.assert_array_equal(ori.cpu().numpy(), o_rets - values)
+    none, rets2, ori2 = hip.gae(dev(rewards), dev(values), d_dones, dev(last_values), dev(last_dones), gamma, 0.95, want_advs=False)
+    assert none is None and torch.equal(rets2, rets) and torch.equal(ori2, ori)
+    _, rets3, none = hip.gae(dev(rewards), dev(values), d_dones, dev(last_values), dev(last_dones), gamma, 0.95,
+                             want_advs_ori=False, want_advs=False)
+    assert none is None and torch.equal(rets3, rets)
+
+
 @pytest.mark.parametrize("n,nepochs", [(2048 * 256, 4), (65536 * 128, 2)])
 def test_index_stream_full_size(mods, n, nepochs):
     """The worker ring draws each epoch's shuffle relative to the identity and the device composes
