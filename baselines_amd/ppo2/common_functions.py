@@ -60,8 +60,13 @@ class _IndexUploader:
             self.issued[s][e].clear()
         self._jobs.put((s, nepochs))
 
-    def close(self):
-        self._jobs.put(None)
+    def close(self, timeout=10.0):
+        """Ends the thread (after the jobs already queued) and waits for it, so that it is not inside a HIP call when the
+        interpreter or its owner goes away; the staging buffers are released with the object."""
+        if self._thread is not None:
+            self._jobs.put(None)
+            self._thread.join(timeout)
+            self._thread = None
 
     def _run(self):
         torch.cuda.set_device(self.device)
@@ -254,7 +259,11 @@ class Model(object):
             self._idx_dev = [torch.empty(N, dtype=torch.int32, device=self.device) for _ in range(noptepochs)]
             if getattr(self, "_uploader", None) is not None:
                 self._uploader.close()
+                self._uploader_finalizer.detach()
             self._uploader = _IndexUploader(self.device, self._pp, N, noptepochs)
+            # the uploader's thread and staging buffers go with the model: the thread references the uploader only
+            import weakref
+            self._uploader_finalizer = weakref.finalize(self, self._uploader.close)
             self._idx_free = [None] * noptepochs      # main-stream event: kernels reading _idx_dev[e] done
             self._copy_stream = torch.cuda.Stream(device=self.device)
             self._side_stats = [None] * noptepochs    # per epoch: (workspace, out) of the advantage statistics taken on the side stream
@@ -464,6 +473,14 @@ class Model(object):
         out = hip.row_mean(self._losses, total, 5)
         comm.allreduce_sum_(out)       # per-rank rows are shares of the global means
         return out
+
+    def close(self):
+        """Ends the index-upload thread of the device path and frees its staging buffers (also runs when the model is
+        garbage-collected or the interpreter exits)."""
+        if getattr(self, "_uploader", None) is not None:
+            self._uploader_finalizer()
+            self._uploader = None
+            self._pp_key = None
 
     # ------------------------------------------------------------------ misc surface
     def get_values(self, obs):

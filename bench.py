@@ -244,6 +244,81 @@ def cpu_baseline(model, ro, cfg, budget_s=20.0):
                        % (reps, N, cfg["nmb"], cfg["noptepochs"]))
 
 
+def build_workload(cfg, device, comm, rank):
+    """Model, synthetic rollout in HBM and the step function (one pass of the hot path over it) of one workload."""
+    from baselines_amd import hip, spaces
+    from baselines_amd.ppo2 import policies
+    from baselines_amd.ppo2.common_functions import Model
+    T, E, A, R = cfg["T"], cfg["E"], cfg["A"], cfg["R"]
+    image = "hwc" in cfg
+    D = None if image else cfg["D"]
+    N = T * E
+    B = N // cfg["nmb"]
+    np.random.seed(1)                     # parameter init stream (ortho_init)
+    policies.reset_scopes()
+    if image:
+        policy = policies.LstmPolicy if cfg.get("nlstm") else policies.CnnPolicy
+        ob_space, ac_space = spaces.Box(0, 255, shape=cfg["hwc"], dtype=np.uint8), spaces.Discrete(A)
+    else:
+        policy = policies.MlpPolicy64 if cfg["upstream"] else policies.MlpPolicy
+        ob_space, ac_space = spaces.Box(-np.inf, np.inf, shape=(D,)), spaces.Box(-1, 1, shape=(A,))
+    model = Model(policy=policy, ob_space=ob_space, ac_space=ac_space,
+                  nbatch_act=E, nbatch_train=B, nsteps=T, ent_coef=cfg["ent_coef"], vf_coef=0.5, max_grad_norm=0.5,
+                  upstream_loss=cfg["upstream"], comm=comm)
+    model.seed_shuffle(0)                 # same index stream on every rank
+    ro = (make_image_rollout if image else make_rollout)(model, cfg, seed=rank, device=device)
+    gamma = 0.99 if R == 1 else [0.99] * R
+
+    def step(events=None):
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        # the scan's own advantage array is left out: the update consumes returns and `returns - values` only, as the
+        # reference's Runner.run hands on mb_returns but not mb_advs (baselines/ppo2/common_functions.py:344, ppo2.py:92)
+        ro.advs_gae, ro.returns, ro.advs_ori = hip.gae(ro.rewards, ro.values, ro.dones, ro.last_values, ro.last_dones,
+                                                       gamma, 0.95, want_advs=False)
+        if events is not None:
+            e1.record()
+            events["gae"].append((e0, e1))
+        if cfg["upstream"]:
+            ro.advs = ro.advs_ori.reshape(T, E)
+        else:
+            ro.advs = hip.compute_advs([200, 120, 0, 0, 0][:R], ro.values.reshape(N, R), ro.advs_ori.reshape(N, R)).reshape(T, E)
+        return model.train_on_rollout(cfg["lr"], cfg["cliprange"], ro, cfg["noptepochs"], B,
+                                      events=None if events is None else events["grad"], more_updates=True)
+    return model, ro, step
+
+
+def gradient_roofline(name, cfg, B, grad_ms):
+    """The minibatch gradient call against the matrix-pipe peak: algorithmic FLOPs of one call over its duration."""
+    image = "hwc" in cfg
+    A, R = cfg["A"], cfg["R"]
+    flops_mb = (cnn_flops_per_sample(cfg["hwc"], A, cfg.get("nlstm", 0)) if image
+                else dense_flops_per_sample(cfg["D"], cfg["hidden"], A, R)) * B
+    fused = (not image) and cfg["hidden"] == (64, 64)
+    fused256 = (not image) and cfg["hidden"] == (256, 128)
+    achieved_tf = flops_mb / (grad_ms * 1e-3) / 1e12
+    peak_tf = MFMA_F32_PEAK_TFLOPS
+    if image and cfg["hwc"][2] * 8 == 32:
+        # conv1 on the bf16 pipe at three products per multiply-add, the rest on the float32 pipe: the peak is the
+        # algorithmic flops over the time both pipes need at their dense rates
+        f_bf16 = cnn_conv1_flops_per_sample(cfg["hwc"]) * B
+        peak_tf = flops_mb / ((flops_mb - f_bf16) / MFMA_F32_PEAK_TFLOPS + 3 * f_bf16 / MFMA_BF16_PEAK_TFLOPS)
+    return {"bound": "mfma",
+            "kernel": ("ppo_grad = mlp_fused16_kernel + fused_finalize_kernel (minibatch gather, forward, loss, "
+                       "backward and weight gradients on fp32 MFMA)") if fused else
+                      ("ppo_grad = gather + mlp_fused256_kernel (forward, loss, input gradients) + mlp_wgrad256_kernel "
+                       "(all weight gradients) + slab reduction, fp32 MFMA") if fused256 else
+                      ("ppo_grad = gather + layered GEMM / implicit-GEMM conv launches (fp32 MFMA; conv1 on uint8 frames as "
+                       "three exact bf16 products per multiply-add) + loss + slab reductions; peak = algorithmic flops over "
+                       "the time the two matrix pipes need at their dense rates"),
+            "achieved": achieved_tf, "peak": peak_tf, "unit": "TFLOP/s",
+            "frac": achieved_tf / peak_tf,
+            "traffic": measured_traffic(name, "ppo2hip::mlp_fused16_kernel<5, false, 2>") if fused else
+                       measured_traffic(name, ("ppo2hip::mlp_fused256_kernel", "ppo2hip::mlp_wgrad256_kernel")) if fused256 else None,
+            "flops_per_launch": flops_mb, "ms_per_launch": grad_ms}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,6 +326,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="mujoco_mlp64", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip the short runs of the other workloads that follow the headline region")
     args = ap.parse_args()
     cfg = WORKLOADS[args.workload]
 
@@ -288,28 +365,16 @@ def main():
         else:
             dist.init_process_group(backend)
         from baselines_amd.common.mpi_adam import DataParallel
-        comm = DataParallel("mpi")
+        comm = DataParallel(os.environ.get("PPO2HIP_BENCH_DP_MODE", "mpi"))
 
-    from baselines_amd import hip, spaces
-    from baselines_amd.ppo2 import policies
-    from baselines_amd.ppo2.common_functions import Model
+    from baselines_amd import hip
 
     T, E, A, R = cfg["T"], cfg["E"], cfg["A"], cfg["R"]
     image = "hwc" in cfg
     D = None if image else cfg["D"]
     N = T * E
     B = N // cfg["nmb"]
-    np.random.seed(1)                     # parameter init stream (ortho_init)
-    if image:
-        policy = policies.LstmPolicy if cfg.get("nlstm") else policies.CnnPolicy
-        ob_space, ac_space = spaces.Box(0, 255, shape=cfg["hwc"], dtype=np.uint8), spaces.Discrete(A)
-    else:
-        policy = policies.MlpPolicy64 if cfg["upstream"] else policies.MlpPolicy
-        ob_space, ac_space = spaces.Box(-np.inf, np.inf, shape=(D,)), spaces.Box(-1, 1, shape=(A,))
-    model = Model(policy=policy, ob_space=ob_space, ac_space=ac_space,
-                  nbatch_act=E, nbatch_train=B, nsteps=T, ent_coef=cfg["ent_coef"], vf_coef=0.5, max_grad_norm=0.5,
-                  upstream_loss=cfg["upstream"], comm=comm)
-    model.seed_shuffle(0)                 # same index stream on every rank
+    model, ro, step = build_workload(cfg, device, comm, rank)
     comm_info = None
     if world > 1:
         # Proof that the collective the timed region uses spans every rank: each rank contributes {its id, 1} to a SUM
@@ -327,32 +392,20 @@ def main():
                      "library_comm_size": native.size if native is not None else None,
                      "epoch_call": "ppo_epoch_dp" if (native is not None and not cfg.get("nlstm")) else "ppo_grad + allreduce + adam_step per minibatch",
                      "allreduce_bytes_per_minibatch": 4 * model.spec.nparams}
-    ro = (make_image_rollout if image else make_rollout)(model, cfg, seed=rank, device=device)
-    gamma = 0.99 if R == 1 else [0.99] * R
-
-    def step(events=None):
-        if events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        # the scan's own advantage array is left out: the update consumes returns and `returns - values` only, as the
-        # reference's Runner.run hands on mb_returns but not mb_advs (baselines/ppo2/common_functions.py:344, ppo2.py:92)
-        ro.advs_gae, ro.returns, ro.advs_ori = hip.gae(ro.rewards, ro.values, ro.dones, ro.last_values, ro.last_dones,
-                                                       gamma, 0.95, want_advs=False)
-        if events is not None:
-            e1.record()
-            events["gae"].append((e0, e1))
-        if cfg["upstream"]:
-            ro.advs = ro.advs_ori.reshape(T, E)
-        else:
-            ro.advs = hip.compute_advs([200, 120, 0, 0, 0][:R], ro.values.reshape(N, R), ro.advs_ori.reshape(N, R)).reshape(T, E)
-        return model.train_on_rollout(cfg["lr"], cfg["cliprange"], ro, cfg["noptepochs"], B,
-                                      events=None if events is None else events["grad"], more_updates=True)
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
 
     # Optional extra untimed updates before the caller's warmup (off by default; reported as "priming_steps").
     priming = int(os.environ.get("PPO2HIP_BENCH_PRIMING", "0"))
@@ -370,11 +423,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt)
     losses = last.cpu().numpy()
     assert np.all(np.isfinite(losses)), "update diverged: %s" % losses
     hip.take_faults()          # raises if an index list was out of range or a whole-sequence launch gave up a wait
@@ -410,7 +459,6 @@ def main():
     torch.cuda.synchronize()
     gae_ms = e0.elapsed_time(e1) / reps
     assert torch.equal(outs[1], ro.returns) and torch.equal(outs[2], ro.advs_ori)
-
     # the same kernel family on a rollout large enough to be bandwidth- rather than latency-bound: the 65536-env x
     # 128-step rollout of the env-sharded configuration, whole, on this one GPU (R = 1)
     def gae_large():
@@ -473,10 +521,48 @@ def main():
     sgemm_tf = 2 * 8192 ** 3 / timed(lambda: torch.matmul(ga, gb), 5) / 1e12
     del src, ga, gb
 
+    # the other workloads, a few steps each behind the headline region: the same step function, timed the same way
+    # (barrier + synchronize on both sides, max over ranks), so that their figures come out of this run too
+    cpu_line = cpu_baseline(model, ro, cfg) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
+    extra = {}
+    if not args.no_extra_workloads:
+        model.close()
+        del model, ro, step, outs
+        torch.cuda.empty_cache()
+        for name in ("mlp_env_shard", "mujoco_fork", "atari_cnn", "atari_lstm", "mujoco_mlp64"):
+            if name == args.workload:
+                continue
+            xcfg = WORKLOADS[name]
+            xN, xB = xcfg["T"] * xcfg["E"], xcfg["T"] * xcfg["E"] // xcfg["nmb"]
+            xsteps, xwarm = (20, 5) if "hwc" not in xcfg else (3, 2)
+            try:
+                xmodel, xro, xstep = build_workload(xcfg, device, comm, rank)
+                for _ in range(xwarm):
+                    xstep()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(xsteps):
+                    xlast = xstep()
+                barrier()
+                xdt = max_over_ranks(time.perf_counter() - t0)
+                xlosses = xlast.cpu().numpy()
+                hip.take_faults()
+                xev = {"gae": [], "grad": []}
+                xstep(xev)
+                torch.cuda.synchronize()
+                xgrad_ms = float(np.median([a.elapsed_time(b) for a, b in xev["grad"]]))
+                roof = gradient_roofline(name, xcfg, xB, xgrad_ms)
+                extra[name] = {"samples_per_s": world * xN * xsteps / xdt, "ms_per_step": xdt / xsteps * 1e3, "steps": xsteps,
+                               "warmup": xwarm, "samples_per_step_per_gpu": xN, "nbatch_train": xB,
+                               "finite_losses": bool(np.all(np.isfinite(xlosses))),
+                               "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "ms_per_launch")}}
+                xmodel.close()
+                del xmodel, xro, xstep, xlast, xev
+            except Exception as ex:          # a failing extra must not take the headline line with it
+                extra[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            torch.cuda.empty_cache()
+
     if rank == 0:
-        flops_mb = (cnn_flops_per_sample(cfg["hwc"], A, cfg.get("nlstm", 0)) if image else dense_flops_per_sample(D, cfg["hidden"], A, R)) * B
-        fused = (not image) and cfg["hidden"] == (64, 64)
-        fused256 = (not image) and cfg["hidden"] == (256, 128)
         if image:
             shape = "Atari-shaped rollout: %dx%dx%d uint8 obs, nature_cnn%s Categorical(%d)" % (
                 cfg["hwc"] + (" + LSTM(%d), env-sequence minibatches," % cfg["nlstm"] if cfg.get("nlstm") else "", A))
@@ -484,13 +570,6 @@ def main():
         else:
             shape = "MuJoCo-shaped rollout: obs_dim=%d act_dim=%d Gaussian MLP%s" % (D, A, str(cfg["hidden"]).replace(" ", ""))
             which = "configs[3] shard" if args.workload == "mlp_env_shard" else "configs[1]"
-        achieved_tf = flops_mb / (grad_ms * 1e-3) / 1e12
-        peak_tf = MFMA_F32_PEAK_TFLOPS
-        if image and cfg["hwc"][2] * 8 == 32:
-            # conv1 on the bf16 pipe at three products per multiply-add, the rest on the float32 pipe: the peak is the
-            # algorithmic flops over the time both pipes need at their dense rates
-            f_bf16 = cnn_conv1_flops_per_sample(cfg["hwc"]) * B
-            peak_tf = flops_mb / ((flops_mb - f_bf16) / MFMA_F32_PEAK_TFLOPS + 3 * f_bf16 / MFMA_BF16_PEAK_TFLOPS)
         gae_bytes = T * E * (16 * R + 1) + E * (4 * R + 1)
         gae_gbs = gae_bytes / (gae_ms * 1e-3) / 1e9
         out = {
@@ -502,19 +581,7 @@ def main():
                                    % (which, shape, E, T, cfg["nmb"], cfg["noptepochs"], "upstream" if cfg["upstream"] else "fork"),
                        "samples_per_step_per_gpu": N, "nbatch_train": B,
                        "parallelism": "env-sharded dp%d, RCCL grad all-reduce (MpiAdam semantics)" % world if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma",
-                         "kernel": ("ppo_grad = mlp_fused16_kernel + fused_finalize_kernel (minibatch gather, forward, loss, "
-                                    "backward and weight gradients on fp32 MFMA)") if fused else
-                                   ("ppo_grad = gather + mlp_fused256_kernel (forward, loss, input gradients) + mlp_wgrad256_kernel "
-                                    "(all weight gradients) + slab reduction, fp32 MFMA") if fused256 else
-                                   ("ppo_grad = gather + layered GEMM / implicit-GEMM conv launches (fp32 MFMA; conv1 on uint8 frames as "
-                                    "three exact bf16 products per multiply-add) + loss + slab reductions; peak = algorithmic flops over "
-                                    "the time the two matrix pipes need at their dense rates"),
-                         "achieved": achieved_tf, "peak": peak_tf, "unit": "TFLOP/s",
-                         "frac": achieved_tf / peak_tf,
-                         "traffic": measured_traffic(args.workload, "ppo2hip::mlp_fused16_kernel<5, false, 2>") if fused else
-                                    measured_traffic(args.workload, ("ppo2hip::mlp_fused256_kernel", "ppo2hip::mlp_wgrad256_kernel")) if fused256 else None,
-                         "flops_per_launch": flops_mb, "ms_per_launch": grad_ms},
+            "roofline": gradient_roofline(args.workload, cfg, B, grad_ms),
             "gae_roofline": {"bound": "hbm", "kernel": "gae_tiled_kernel", "achieved": gae_gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": gae_gbs / HBM_PEAK_GBS, "bytes_per_launch": gae_bytes,
                              "traffic": measured_traffic(args.workload, "ppo2hip::gae_tiled_kernel"),
@@ -527,8 +594,10 @@ def main():
         }
         if comm_info is not None:
             out["comm"] = comm_info
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, ro, cfg)
+        if extra:
+            out["workloads"] = extra
+        if cpu_line is not None:
+            out["cpu_baseline"] = cpu_line
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

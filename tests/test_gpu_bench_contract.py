@@ -28,6 +28,13 @@ def test_bench_line():
     g = d["gae_roofline"]
     assert g["bound"] == "hbm" and g["unit"] == "GB/s" and 0 < g["frac"] < 1
     assert d["value"] > 1e6 and abs(d["value"] - 524288 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    # the other four workloads ride in the same line, a few steps each
+    w = d["workloads"]
+    assert sorted(w) == ["atari_cnn", "atari_lstm", "mlp_env_shard", "mujoco_fork"]
+    for name, x in w.items():
+        assert "error" not in x, (name, x)
+        assert x["finite_losses"] and x["samples_per_s"] > 1e4 and 0 < x["roofline"]["frac"] < 1
+        assert abs(x["samples_per_s"] - x["samples_per_step_per_gpu"] / (x["ms_per_step"] * 1e-3)) / x["samples_per_s"] < 1e-6
 
 
 def test_bench_two_ranks_rehearsal():
@@ -39,7 +46,8 @@ def test_bench_two_ranks_rehearsal():
     env = dict(os.environ, PPO2HIP_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
     # started bare, as `python bench.py --gpus 2`: the script launches its own two rank processes
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-extra-workloads"],
                          cwd=ROOT, env=env, check=True, capture_output=True, text=True, timeout=280).stdout
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out
