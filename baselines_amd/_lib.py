@@ -118,6 +118,13 @@ _SIGS = {
     "ppo2hip_ppo_epoch_dp": (c_int, [POINTER(PolicyDesc), POINTER(LossDesc), _P, _P, _P, _P, POINTER(Rollout), _P, c_int64,
                                      c_int64, _P, c_float, c_double, c_int64, c_double, c_double, c_double, c_double, _P,
                                      _P, c_size_t, _P, c_void_p, c_double, _P]),
+    "ppo2hip_filter_owned_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "ppo2hip_filter_owned_i32": (c_int, [_P, c_int64, c_int, c_int32, c_int32, _P, c_int64, _P, _P, c_size_t, _P]),
+    "ppo2hip_adv_stats_owned_workspace_bytes": (c_size_t, [c_int]),
+    "ppo2hip_adv_stats_owned": (c_int, [_P, c_int, _P, c_int64, c_int, c_int32, c_int32, c_int, c_int, _P, _P, _P]),
+    "ppo2hip_ppo_epoch_shares": (c_int, [POINTER(PolicyDesc), POINTER(LossDesc), _P, _P, _P, _P, POINTER(Rollout), _P, c_int64,
+                                         POINTER(c_int64), c_int, _P, c_float, c_double, c_double, c_int64, c_double, c_double,
+                                         c_double, c_double, _P, _P, c_size_t, _P, c_void_p, _P]),
     "ppo2hip_gemm_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
 }
 

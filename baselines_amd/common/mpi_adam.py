@@ -167,6 +167,13 @@ class DataParallel:
         keep = (env >= e0) & (env < e1)
         return (mbinds[keep] - e0 * nsteps).astype(np.int32)
 
+    def local_envs(self, mbenvinds, nenvs_global):
+        """Global env numbers of one env-sequence minibatch (baselines/ppo2/ppo2.py:131-133) -> the envs this rank
+        owns, in list order, re-based to its own numbering."""
+        e0, e1 = self.env_range(nenvs_global)
+        mbenvinds = np.asarray(mbenvinds)
+        return (mbenvinds[(mbenvinds >= e0) & (mbenvinds < e1)] - e0).astype(np.int32)
+
 
 class MpiAdam:
     """The reference's optimiser object (mpi_adam.py:6-50) over a device parameter arena:

@@ -206,3 +206,37 @@ extern "C" int ppo2hip_ppo_epoch_dp(const ppo2hip_policy_desc *desc, const ppo2h
     }
     return PPO2HIP_OK;
 }
+
+extern "C" int ppo2hip_ppo_epoch_shares(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss, float *params,
+                                        float *grads, float *adam_m, float *adam_v, const ppo2hip_rollout *rollout,
+                                        const int32_t *idx, int64_t idx_stride, const int64_t *counts, int nmb,
+                                        const double *stats, float cliprange, double inv_count, double lr,
+                                        int64_t t_first, double beta1, double beta2, double epsilon,
+                                        double max_grad_norm, float *losses, void *workspace, size_t workspace_bytes,
+                                        void *adam_scratch, ppo2hip_comm *comm, void *stream) {
+    PPO2HIP_REQUIRE(desc && idx && counts && adam_m && adam_v && adam_scratch && losses && grads, "ppo_epoch_shares: null pointer");
+    PPO2HIP_REQUIRE(nmb >= 1 && idx_stride >= 1, "ppo_epoch_shares: nmb=%d idx_stride=%lld", nmb, (long long)idx_stride);
+    PPO2HIP_REQUIRE(desc->kind == PPO2HIP_POLICY_MLP || desc->kind == PPO2HIP_POLICY_CNN,
+                    "ppo_epoch_shares: feed-forward policies only (recurrent minibatches are env sequences)");
+    const int64_t P = ppo2hip_param_count(desc);
+    if (P < 0) return PPO2HIP_EINVAL;
+    for (int j = 0; j < nmb; j++) {
+        PPO2HIP_REQUIRE(counts[j] >= 0 && counts[j] <= idx_stride, "ppo_epoch_shares: count %lld of minibatch %d outside [0, %lld]",
+                        (long long)counts[j], j, (long long)idx_stride);
+        int rc;
+        if (counts[j] > 0) {
+            rc = ppo2hip_ppo_grad(desc, loss, params, rollout, idx + (int64_t)j * idx_stride, counts[j], nullptr, 0,
+                                  stats ? stats + 3 * j : nullptr, cliprange, inv_count, grads, losses + 8 * j, workspace,
+                                  workspace_bytes, stream);
+            if (rc) return rc;
+        } else {        // none of this minibatch's samples live here: this rank adds zeros to the sums
+            PPO2HIP_CHECK_HIP(hipMemsetAsync(grads, 0, (size_t)P * sizeof(float), (hipStream_t)stream));
+            PPO2HIP_CHECK_HIP(hipMemsetAsync(losses + 8 * j, 0, 8 * sizeof(float), (hipStream_t)stream));
+        }
+        if ((rc = ppo2hip_allreduce_grads(comm, grads, P, stream))) return rc;
+        rc = ppo2hip_adam_step(params, grads, adam_m, adam_v, P, lr, t_first + j, beta1, beta2, epsilon, 1.0,
+                               max_grad_norm, adam_scratch, stream);
+        if (rc) return rc;
+    }
+    return PPO2HIP_OK;
+}

@@ -154,6 +154,11 @@ int gather_states(const float *states, const int32_t *envs, int nenv_mb, int wid
 // restated as a gather).
 // ---------------------------------------------------------------------------------------
 namespace ppo2hip {
+// word 1 of the fault array receives what word 0 held; word 0 is cleared by the same atomic, so a bit raised by a kernel
+// on another stream lands either in this read or in the next one, never in neither
+__global__ void take_faults_kernel(unsigned *words) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) words[1] = atomicExch(&words[0], 0u);
+}
 __global__ void compose_kernel(const int32_t *__restrict__ prev, const int32_t *__restrict__ sigma,
                                int32_t *__restrict__ out, int64_t n, unsigned *fault) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -181,9 +186,11 @@ extern "C" int ppo2hip_take_faults(uint32_t *bits, void *stream) {
     if (!fault) return PPO2HIP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     uint32_t host = 0;
-    PPO2HIP_CHECK_HIP(hipMemcpyAsync(&host, fault, sizeof(host), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(take_faults_kernel, dim3(1), dim3(64), 0, s, fault);
+    int rc = check_launch("take_faults_kernel");
+    if (rc) return rc;
+    PPO2HIP_CHECK_HIP(hipMemcpyAsync(&host, fault + 1, sizeof(host), hipMemcpyDeviceToHost, s));
     PPO2HIP_CHECK_HIP(hipStreamSynchronize(s));
-    if (host) PPO2HIP_CHECK_HIP(hipMemsetAsync(fault, 0, sizeof(host), s));
     *bits = host;
     return PPO2HIP_OK;
 }

@@ -305,7 +305,7 @@ class LegacyShuffler:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:      # module globals may be gone at interpreter exit
             lib.ppo2hip_rng_destroy(h)
 
     def seed(self, seed):
@@ -365,7 +365,7 @@ class PermPipeline:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:      # module globals may be gone at interpreter exit
             lib.ppo2hip_perm_destroy(h)
 
     def begin(self, nepochs, relative=False, buffer_set=0):
@@ -711,7 +711,7 @@ class NativeComm:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:      # module globals may be gone at interpreter exit
             lib.ppo2hip_comm_destroy(h)
 
     def allreduce_sum_(self, t):
@@ -779,6 +779,71 @@ def ppo_epoch(spec, loss_desc, params, grads, m, v, rollout, idx, nbatch_train, 
                                 float(max_grad_norm or 0.0), _ptr(losses), _ptr(workspace), have, _ptr(adam_scratch),
                                 _stream()), "ppo_epoch")
 
+
+# --------------------------------------------------------------------------------------
+# one global permutation over env-sharded ranks: ownership filter, statistics and epoch call over a rank's shares
+# --------------------------------------------------------------------------------------
+
+def filter_owned(idx, nbatch_train, nmb, lo, hi, out, out_stride, counts, workspace=None):
+    """Minibatch j of the global list ``idx`` ([nmb * nbatch_train] int32) -> this rank's entries (sample numbers in
+    [lo, hi), re-based to 0) at ``out[j * out_stride:]`` in list order, their number in ``counts[j]`` (device int32)."""
+    idx = _dev(idx, torch.int32, "idx")
+    out = _dev(out, torch.int32, "out")
+    counts = _dev(counts, torch.int32, "counts")
+    if idx.numel() < nmb * nbatch_train or out.numel() < nmb * out_stride or counts.numel() < nmb:
+        raise ValueError("filter_owned: idx, out or counts too short")
+    wsb = lib.ppo2hip_filter_owned_workspace_bytes(int(nbatch_train), int(nmb))
+    if workspace is None:
+        workspace = torch.empty(wsb, dtype=torch.uint8, device=idx.device)
+    have = workspace.numel() * workspace.element_size()
+    check(lib.ppo2hip_filter_owned_i32(_ptr(idx), int(nbatch_train), int(nmb), int(lo), int(hi), _ptr(out), int(out_stride),
+                                       _ptr(counts), _ptr(workspace), have, _stream()), "filter_owned")
+    return out, counts
+
+
+def adv_stats_owned(advs, idx, nbatch_train, nmb, lo, hi, T, E, workspace=None, out=None):
+    """{sum a, sum a^2, entries owned} of this rank's share of every global minibatch (float64 [nmb, 3], device);
+    ``advs`` is the rank's own time-major [T, E] array."""
+    if advs.dtype not in (torch.float32, torch.float64) or not advs.is_cuda or not advs.is_contiguous():
+        raise TypeError("advs must be a contiguous float32/float64 device tensor")
+    idx = _dev(idx, torch.int32, "idx")
+    if idx.numel() < nmb * nbatch_train:
+        raise ValueError("idx shorter than nmb * nbatch_train")
+    if T * E != advs.numel() or hi - lo > T * E:
+        raise ValueError("advs must hold T*E entries and the owned range must fit them")
+    wsb = lib.ppo2hip_adv_stats_owned_workspace_bytes(int(nmb))
+    if workspace is None:
+        workspace = torch.empty(wsb, dtype=torch.uint8, device=advs.device)
+    elif workspace.numel() * workspace.element_size() < wsb:
+        raise ValueError("adv_stats_owned workspace too small")
+    if out is None:
+        out = torch.empty((nmb, 3), dtype=torch.float64, device=advs.device)
+    check(lib.ppo2hip_adv_stats_owned(_ptr(advs), int(advs.dtype == torch.float64), _ptr(idx), int(nbatch_train), int(nmb),
+                                      int(lo), int(hi), int(T), int(E), _ptr(workspace), _ptr(out), _stream()), "adv_stats_owned")
+    return out
+
+
+def ppo_epoch_shares(spec, loss_desc, params, grads, m, v, rollout, idx, idx_stride, counts, stats, cliprange, inv_count, lr,
+                     t_first, losses, workspace, adam_scratch, max_grad_norm=0.0, beta1=0.9, beta2=0.999, epsilon=1e-5,
+                     comm=None):
+    """An epoch over this rank's shares of the global minibatches (``counts``: host ints, one per minibatch): gradient
+    sums scaled by ``inv_count`` = 1 / global minibatch size, SUM all-reduce over ``comm`` (a NativeComm or None), Adam."""
+    for x, name in ((params, "params"), (grads, "grads"), (m, "m"), (v, "v"), (losses, "losses")):
+        _dev(x, torch.float32, name)
+    _dev(idx, torch.int32, "idx")
+    _dev(stats, torch.float64, "stats")
+    nmb, P = len(counts), spec.nparams
+    if idx.numel() < nmb * idx_stride or losses.numel() < 8 * nmb or stats.numel() < 3 * nmb:
+        raise ValueError("ppo_epoch_shares: idx, losses or stats too short")
+    have = workspace.numel() * workspace.element_size()
+    if have < spec.grad_workspace_bytes(max(max(counts), 1)):
+        raise ValueError("grad workspace too small")
+    c_counts = (ctypes.c_int64 * nmb)(*[int(c) for c in counts])
+    check(lib.ppo2hip_ppo_epoch_shares(ctypes.byref(spec.desc), ctypes.byref(loss_desc), _ptr(params), _ptr(grads), _ptr(m),
+                                       _ptr(v), ctypes.byref(rollout.c), _ptr(idx), int(idx_stride), c_counts, nmb, _ptr(stats),
+                                       float(cliprange), float(inv_count), float(lr), int(t_first), beta1, beta2, epsilon,
+                                       float(max_grad_norm or 0.0), _ptr(losses), _ptr(workspace), have, _ptr(adam_scratch),
+                                       comm._h if comm is not None else None, _stream()), "ppo_epoch_shares")
 
 def row_mean(rows, nrows, ncols, scale=None):
     """scale * column sums of the first ``nrows`` rows and ``ncols`` columns of a float32 [*, stride] tensor

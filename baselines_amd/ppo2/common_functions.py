@@ -310,7 +310,7 @@ class Model(object):
                               ro.dones if spec.recurrent else None, ro.states)
         comm = self.comm if (self.comm is not None and self.comm.size > 1) else None
         if comm is not None and comm.mode == "global":
-            return self._train_on_rollout_global(lr, cliprange, ro, rref, noptepochs, nbatch_train)
+            return self._train_on_rollout_global(lr, cliprange, ro, rref, noptepochs, nbatch_train, more_updates)
         if not spec.recurrent:
             if N % nbatch_train != 0:
                 raise AssertionError("nbatch %% nbatch_train != 0")   # baselines/ppo2/ppo2.py:74
@@ -426,52 +426,162 @@ class Model(object):
         inflight.append(queued)
         return out
 
-    def _train_on_rollout_global(self, lr, cliprange, ro, rref, noptepochs, nbatch_train):
-        """Data-parallel update that reproduces the single-process one: every rank draws the
-        same GLOBAL permutation (over all ranks' envs, ``nbatch_train`` = global minibatch size),
-        keeps the rows of the envs it owns, and the ranks all-reduce {sum a, sum a^2, n},
-        gradient sums (scaled by 1/B_global) and loss sums."""
+    def _train_on_rollout_global(self, lr, cliprange, ro, rref, noptepochs, nbatch_train, more_updates=False):
+        """Data-parallel update that reproduces the single-process one: every rank draws the same GLOBAL minibatch
+        order (baselines/ppo2/ppo2.py:110-116 over all ranks' envs; ``nbatch_train`` = global minibatch size) with the
+        same index pipeline as the single-process path, and works on the entries whose env it owns.
+
+        Per epoch, on the side stream behind the index list: the rank's {sum a, sum a^2, n} per minibatch straight off
+        the global list, the ownership filter (compact + count) and a copy of the counts to page-locked memory.  On the
+        main stream: ONE all-reduce of the [nmb, 3] statistics per epoch, then per minibatch gradient sums scaled by
+        1/B_global, the SUM all-reduce of the gradient arena and Adam — one library call per epoch on the library's
+        communicator.  The host waits for the side stream's counts only (queued ahead of the main stream's work), never
+        for the main stream."""
         spec, comm = self.spec, self.comm
         if spec.recurrent:
-            raise NotImplementedError("global-permutation data parallelism: feed-forward policies only")
-        T, E = ro.T, ro.E
-        Ng = T * E * comm.size
+            return self._train_on_rollout_global_recurrent(lr, cliprange, ro, rref, noptepochs, nbatch_train)
+        T, E, G = ro.T, ro.E, comm.size
+        Nl = T * E
+        Ng = Nl * G
+        if Ng >= 2 ** 31:
+            raise ValueError("global sample numbers are int32: %d samples over all ranks is too many" % Ng)
         if Ng % nbatch_train != 0:
-            raise AssertionError("nbatch %% nbatch_train != 0")
+            raise AssertionError("nbatch %% nbatch_train != 0")   # baselines/ppo2/ppo2.py:74
         nmb = Ng // nbatch_train
+        lo, hi = comm.rank * Nl, (comm.rank + 1) * Nl
+        main = torch.cuda.current_stream()
+        pp = self._index_pipeline(Ng, noptepochs)
+        if not self._pp_ahead:
+            self._begin_index_job(pp, noptepochs)
+        self._pp_ahead = False
         total = nmb * noptepochs
         if self._losses.shape[0] < total:
             self._losses = torch.zeros((total, 8), dtype=torch.float32, device=self.device)
-        if not hasattr(self, "_shuffler"):
-            self._shuffler = hip.LegacyShuffler(0)
-            self._own_stream = False
-        if not self._own_stream:
-            self._shuffler.adopt_numpy()
-        inds = np.arange(Ng, dtype=np.int32)
-        stat_ws = self._stats_workspace(1)
+        key = (Ng, nbatch_train, noptepochs)
+        if getattr(self, "_share_key", None) != key:
+            dv = self.device
+            self._share = [dict(local=torch.empty(Ng, dtype=torch.int32, device=dv),
+                                counts=torch.empty(nmb, dtype=torch.int32, device=dv),
+                                counts_host=torch.empty(nmb, dtype=torch.int32, pin_memory=True),
+                                stats=torch.empty((nmb, 3), dtype=torch.float64, device=dv),
+                                stat_ws=torch.empty(int(_lib.lib.ppo2hip_adv_stats_owned_workspace_bytes(nmb)), dtype=torch.uint8, device=dv),
+                                filter_ws=torch.empty(int(_lib.lib.ppo2hip_filter_owned_workspace_bytes(nbatch_train, nmb)),
+                                                      dtype=torch.uint8, device=dv))
+                           for _ in range(noptepochs)]
+            self._share_key = key
+        native = comm.native()
+        advs_ready = torch.cuda.Event()
+        advs_ready.record(main)
         row = 0
-        for _ in range(noptepochs):
-            self._shuffler.shuffle(inds)
-            for j in range(nmb):
-                local = comm.local_minibatch(inds[j * nbatch_train:(j + 1) * nbatch_train], T, E * comm.size)
-                Bl = int(local.size)
-                stats = torch.zeros((1, 3), dtype=torch.float64, device=self.device)
-                if Bl:
-                    d_idx = torch.from_numpy(local).to(self.device)
-                    hip.adv_stats(ro.advs, d_idx, Bl, 1, T, E, stat_ws, stats)
-                comm.allreduce_sum_(stats)
-                if Bl:
-                    hip.ppo_grad(spec, self.loss_desc, self.arena.theta, rref, d_idx, Bl, stats[0], cliprange,
-                                 1.0 / nbatch_train, self.grads, self._losses[row], self._workspace(Bl))
-                else:
-                    self.grads.zero_()
-                    self._losses[row].zero_()
-                self._apply(lr)
-                row += 1
+        for e in range(noptepochs):
+            sig, sig_ready = self._uploader.wait(self._pp_set, e)
+            d_idx = sig if e == 0 else self._idx_dev[e]
+            b = self._share[e]
+            with torch.cuda.stream(self._copy_stream):
+                self._copy_stream.wait_event(sig_ready)
+                if self._idx_free[e] is not None:
+                    self._copy_stream.wait_event(self._idx_free[e])      # also frees this epoch's share buffers
+                if e == 0:
+                    self._copy_stream.wait_event(advs_ready)
+                else:           # the running order is a device gather through the order of the epoch before
+                    hip.compose(d_prev, sig, d_idx)
+                hip.adv_stats_owned(ro.advs, d_idx, nbatch_train, nmb, lo, hi, T, E, b["stat_ws"], out=b["stats"])
+                hip.filter_owned(d_idx, nbatch_train, nmb, lo, hi, b["local"], nbatch_train, b["counts"], b["filter_ws"])
+                b["counts_host"].copy_(b["counts"], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._copy_stream)
+            d_prev = d_idx
+            self._set_copied[self._pp_set] = sig_ready
+            main.wait_event(ev)
+            comm.allreduce_sum_(b["stats"])          # rows become {sum a, sum a^2, B_global}: one collective per epoch
+            ev.synchronize()                         # the sizes of this rank's shares (side stream only)
+            counts = [int(c) for c in b["counts_host"].tolist()]
+            ws = self._workspace(max(max(counts), 1))
+            if native is not None:
+                if -(-self.adam_t // 100) * 100 < self.adam_t + nmb:
+                    comm.check_synced(self.arena.theta, wait=False)      # an Adam step count of this epoch is a multiple of 100
+                hip.ppo_epoch_shares(spec, self.loss_desc, self.arena.theta, self.grads, self.adam_m, self.adam_v, rref,
+                                     b["local"], nbatch_train, counts, b["stats"], cliprange, 1.0 / nbatch_train, lr,
+                                     self.adam_t + 1, self._losses[row:row + nmb], ws, self._adam_scratch,
+                                     max_grad_norm=self.max_grad_norm, comm=native)
+                self.adam_t += nmb
+            else:       # torch.distributed carries the gradients: one minibatch per round of Python calls
+                for j in range(nmb):
+                    c = counts[j]
+                    if c:
+                        hip.ppo_grad(spec, self.loss_desc, self.arena.theta, rref, b["local"][j * nbatch_train:j * nbatch_train + c],
+                                     c, b["stats"][j], cliprange, 1.0 / nbatch_train, self.grads, self._losses[row + j], ws)
+                    else:
+                        self.grads.zero_()
+                        self._losses[row + j].zero_()
+                    self._apply(lr)
+            row += nmb
+            done = torch.cuda.Event()
+            done.record(main)
+            self._idx_free[e] = done
+            self._uploader.free[self._pp_set][e] = done
+        pp.wait_all()
         if not self._own_stream:
             self._shuffler.release_numpy()
+        elif more_updates:
+            self._begin_index_job(pp, noptepochs)
+            self._pp_ahead = True
         out = hip.row_mean(self._losses, total, 5)
         comm.allreduce_sum_(out)       # per-rank rows are shares of the global means
+        comm.poll_checks()
+        queued = torch.cuda.Event()
+        queued.record(main)
+        self.__dict__.setdefault("_updates_inflight", []).append(queued)
+        return out
+
+    def _train_on_rollout_global_recurrent(self, lr, cliprange, ro, rref, noptepochs, nbatch_train):
+        """Env-sequence minibatches (baselines/ppo2/ppo2.py:124-136) over env-sharded ranks with one global env order:
+        every rank shuffles ``arange(E_global)`` from the same ``np.random`` state and keeps the envs it owns; the
+        whole update's {sum a, sum a^2, n} rows are all-reduced in one collective, gradient sums (scaled by
+        1 / global minibatch size) once per minibatch."""
+        spec, comm = self.spec, self.comm
+        T, E, G = ro.T, ro.E, comm.size
+        Eg = E * G
+        envsperbatch = nbatch_train // T
+        if envsperbatch < 1 or Eg % envsperbatch != 0:
+            raise AssertionError("nenvs must be a multiple of the envs per minibatch")
+        nmb = Eg // envsperbatch
+        total = nmb * noptepochs
+        if self._losses.shape[0] < total:
+            self._losses = torch.zeros((total, 8), dtype=torch.float32, device=self.device)
+        envinds = np.arange(Eg, dtype=np.int32)
+        lists = []
+        for _ in range(noptepochs):
+            np.random.shuffle(envinds)                       # :130, over all ranks' envs
+            for start in range(0, Eg, envsperbatch):
+                lists.append(comm.local_envs(envinds[start:start + envsperbatch], Eg))
+        env_cat = np.concatenate(lists)
+        flat_cat = (env_cat[:, None].astype(np.int64) * T + np.arange(T, dtype=np.int64)[None, :]).astype(np.int32).ravel()   # :134
+        d_env = torch.from_numpy(env_cat).to(self.device)
+        d_flat = torch.from_numpy(flat_cat).to(self.device)
+        stats = torch.zeros((total, 3), dtype=torch.float64, device=self.device)
+        stat_ws = self._stats_workspace(1)
+        off = 0
+        for k, l in enumerate(lists):
+            if l.size:
+                hip.adv_stats(ro.advs, d_flat[off * T:(off + l.size) * T], l.size * T, 1, T, E, stat_ws, out=stats[k:k + 1])
+            off += l.size
+        comm.allreduce_sum_(stats)
+        ws = self._workspace(max(max(l.size for l in lists), 1) * T)
+        off = 0
+        for k, l in enumerate(lists):
+            n = int(l.size)
+            if n:
+                hip.ppo_grad(spec, self.loss_desc, self.arena.theta, rref, d_flat[off * T:(off + n) * T], n * T, stats[k], cliprange,
+                             1.0 / nbatch_train, self.grads, self._losses[k], ws, d_env[off:off + n], T)
+            else:
+                self.grads.zero_()
+                self._losses[k].zero_()
+            self._apply(lr)
+            off += n
+        out = hip.row_mean(self._losses, total, 5)
+        comm.allreduce_sum_(out)
+        comm.poll_checks()
         return out
 
     def close(self):

@@ -431,6 +431,38 @@ int ppo2hip_ppo_epoch_dp(const ppo2hip_policy_desc *desc, const ppo2hip_loss_des
                          size_t workspace_bytes, void *adam_scratch, ppo2hip_comm *comm, double grad_scale,
                          void *stream);
 
+/* Env-sharded data parallelism in which every rank draws the SAME global minibatch order (the np.random stream of
+ * baselines/ppo2/ppo2.py:110-116 over all ranks' samples) and works on the entries whose env it owns, so that N ranks
+ * reproduce the single-process update up to summation order.  A rank owns a contiguous block of envs, i.e. the
+ * env-major flat sample numbers [lo, hi); its own sample numbers are s - lo.  All pointers DEVICE unless marked.
+ *
+ * ppo2hip_filter_owned_i32: idx holds nmb global minibatches of nbatch_train entries back to back.  For minibatch j
+ * the owned entries, re-based, in list order, go to out[j*out_stride ...] and their number to counts[j]; up to 64
+ * slots behind them are set to sample 0.  out_stride >= the largest share expected (nbatch_train always suffices);
+ * a larger share raises PPO2HIP_FAULT_INDEX_RANGE and is cut.
+ *   workspace : ppo2hip_filter_owned_workspace_bytes(nbatch_train, nmb) */
+size_t ppo2hip_filter_owned_workspace_bytes(int64_t nbatch_train, int nmb);
+int ppo2hip_filter_owned_i32(const int32_t *idx, int64_t nbatch_train, int nmb, int32_t lo, int32_t hi, int32_t *out,
+                             int64_t out_stride, int32_t *counts, void *workspace, size_t workspace_bytes, void *stream);
+/* ppo2hip_adv_stats over this rank's share of each global minibatch: stats[j] = {sum a, sum a^2, entries owned}
+ * (float64, fixed summation order) with advs the rank's own time-major [T, E] array; SUM-all-reduced over the ranks
+ * (ppo2hip_allreduce_f64) the rows are the statistics of baselines/ppo2/common_functions.py:67 over the whole minibatch.
+ *   workspace : ppo2hip_adv_stats_owned_workspace_bytes(nmb) */
+size_t ppo2hip_adv_stats_owned_workspace_bytes(int nmb);
+int ppo2hip_adv_stats_owned(const void *advs, int adv_f64, const int32_t *idx, int64_t nbatch_train, int nmb, int32_t lo,
+                            int32_t hi, int T, int E, void *workspace, double *stats, void *stream);
+/* An epoch over the shares: for minibatch j, ppo2hip_ppo_grad on idx[j*idx_stride ...] with counts[j] (HOST int64,
+ * 0 allowed: the rank contributes zeros) entries, means taken with `inv_count` (1 / the GLOBAL minibatch size) and the
+ * all-reduced `stats` rows, then the SUM all-reduce of the gradient arena over `comm` and the optimiser step
+ * (gradient scale 1): gradient sums, not per-rank means, are what the ranks add.  losses [nmb, 8]: each rank's rows are
+ * its shares of the global means.  Every rank makes the same call with the same nmb. */
+int ppo2hip_ppo_epoch_shares(const ppo2hip_policy_desc *desc, const ppo2hip_loss_desc *loss, float *params, float *grads,
+                             float *adam_m, float *adam_v, const ppo2hip_rollout *rollout, const int32_t *idx,
+                             int64_t idx_stride, const int64_t *counts, int nmb, const double *stats, float cliprange,
+                             double inv_count, double lr, int64_t t_first, double beta1, double beta2, double epsilon,
+                             double max_grad_norm, float *losses, void *workspace, size_t workspace_bytes,
+                             void *adam_scratch, ppo2hip_comm *comm, void *stream);
+
 /* out[c] = scale * sum_r rows[r*stride + c] for c < ncols (<= 16): the mean of the per-minibatch
  * loss rows that learn reports, baselines/ppo2/ppo2.py:139 (scale = 1/nrows; data-parallel runs
  * fold 1/size in and SUM-all-reduce the result).  float64 sums, fixed order. */

@@ -129,3 +129,36 @@ def test_env_sharding_and_ownership_filter():
     np.testing.assert_array_equal(comm.local_minibatch(mb, T, 16), [0, 4, 19, 1])
     with pytest.raises(ValueError):
         comm.env_range(18)
+    # env-sequence minibatches: the owned envs of a global env list, in list order, re-based
+    np.testing.assert_array_equal(comm.local_envs(np.array([11, 3, 8, 15, 9, 12]), 16), [3, 0, 1])
+    assert comm.local_envs(np.array([0, 1, 14]), 16).size == 0
+
+
+def _recurrent_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from baselines_amd.common.mpi_adam import DataParallel
+    comm = DataParallel("global")
+    E, T, envsperbatch = 12, 4, 3
+    np.random.seed(21)                       # the same env order on every rank
+    got = []
+    for envs_mb, _ in (x for ep in perm.recurrent_minibatch_indices(E, T, envsperbatch * T, 2) for x in ep):
+        mine = comm.local_envs(envs_mb, E) + comm.env_range(E)[0]
+        # the ranks' shares of the minibatch, gathered: their sizes through the collective the product uses
+        n = torch.tensor([float(mine.size)], dtype=torch.float64)
+        comm.allreduce_sum_(n)
+        assert int(n.item()) == envsperbatch
+        box = [None] * world
+        dist.all_gather_object(box, mine.tolist())
+        got.append((sorted(envs_mb.tolist()), sorted(box[0] + box[1])))
+    if rank == 0:
+        out.put(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_recurrent_global_env_lists_partition_every_minibatch():
+    """Two gloo ranks draw the env-sequence minibatches of baselines/ppo2/ppo2.py:124-136 from the same stream; each keeps
+    the envs it owns: together the shares are the minibatch, each env exactly once."""
+    for want, union in util.run_ranks(_recurrent_worker, 2):
+        assert want == union

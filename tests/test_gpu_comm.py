@@ -7,7 +7,8 @@
     (tests/golden/reference_mpi_adam.npz), two ranks played by a communicator that adds the other rank's recorded
     gradient.
   * Two ranks sharing this box's GPU in "mpi" mode (per-rank shuffles and normalisation, SUM all-reduce, 1/size,
-    baselines/common/mpi_adam.py:24-28; gradients staged through the host over gloo) against the oracle run the same way.
+    baselines/common/mpi_adam.py:24-28; gradients staged through the host over gloo) against the oracle run the same way,
+    for the MLP and for cnn + LSTM with env-sequence minibatches (baselines/ppo2/ppo2.py:124-137).
 """
 import ctypes
 import os
@@ -193,3 +194,95 @@ def test_two_ranks_mpi_mode_matches_the_oracle():
     diff = float(np.abs(theta - want).max())
     print("two ranks, mpi mode: parameter diff vs oracle %.3e" % diff)
     assert diff <= 2e-6
+
+
+# ---- cnn + LSTM, env-sequence minibatches, two ranks in "mpi" mode --------------------------------------
+R_HWC, R_NACT, R_T, R_E, R_NLSTM = (36, 36, 2), 4, 6, 8, 32
+
+
+def _recurrent_data():
+    shapes = tfgraph.cnn_param_shapes(R_HWC[2], R_NACT, "lstm", R_NLSTM, flat=util.cnn_flat(R_HWC[0], R_HWC[1]))
+    params = util.make_params(shapes, 51, pi_scale=0.5, jitter=0.002)
+    rng = np.random.RandomState(52)
+    ro = util.synthetic_cnn_rollout(rng, R_T, R_E, R_HWC, R_NACT, params, kind="lstm", nlstm=R_NLSTM)
+    ro["states"] = (0.2 * rng.randn(R_E, 2 * R_NLSTM)).astype(np.float32)
+    return params, ro
+
+
+def _mpi_recurrent_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from baselines_amd import hip, spaces
+    from baselines_amd.common.mpi_adam import DataParallel
+    from baselines_amd.ppo2 import policies
+    from baselines_amd.ppo2.common_functions import DeviceRollout, Model
+    comm = DataParallel("mpi")
+    params, ro = _recurrent_data()
+    e0, e1 = comm.env_range(R_E)
+    Es = e1 - e0
+    nbt = (Es // 2) * R_T
+
+    class SmallLstm(policies.LstmPolicy):
+        def __init__(self, *a, **k):
+            super().__init__(*a, nlstm=R_NLSTM, **k)
+
+    policies.reset_scopes()
+    model = Model(policy=SmallLstm, ob_space=spaces.Box(0, 255, shape=R_HWC, dtype=np.uint8), ac_space=spaces.Discrete(R_NACT),
+                  nbatch_act=Es, nbatch_train=nbt, nsteps=R_T, ent_coef=0.01, vf_coef=0.5, max_grad_norm=0.5, upstream_loss=True,
+                  comm=comm)
+    model.arena.set_dict(params)
+    sl = lambda a: dev(a[:, e0:e1])
+    d = DeviceRollout(R_T, Es, sl(ro["obs"]), sl(ro["actions"]), sl(ro["rewards"]), sl(ro["values"]), sl(ro["neglogpacs"]),
+                      sl(ro["dones"]), dev(ro["last_values"][e0:e1]), dev(ro["last_dones"][e0:e1]), states=dev(ro["states"][e0:e1]))
+    _, d.returns, d.advs_ori = hip.gae(d.rewards, d.values, d.dones, d.last_values, d.last_dones, 0.99, 0.95, want_advs=False)
+    d.advs = d.advs_ori.reshape(R_T, Es)
+    np.random.seed(5)                       # every rank shuffles its own envs (here: from the same seed)
+    losses = model.train_on_rollout(2.5e-4, 0.1, d, NEP, nbt).cpu().numpy()
+    hip.take_faults()
+    assert comm.check_synced(model.arena.theta)
+    if rank == 0:
+        out.put((losses, model.arena.theta.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_mpi_mode_recurrent_matches_the_oracle():
+    """cnn + LSTM over two ranks: each rank runs the env-sequence minibatch loop of baselines/ppo2/ppo2.py:124-137 on its own
+    envs; per minibatch the gradients are summed over the ranks and divided by their number (MpiAdam.update,
+    baselines/common/mpi_adam.py:24-28) before clip + Adam.  The oracle evaluates both ranks' minibatches at the shared
+    parameters and applies the mean gradient."""
+    losses, theta = util.run_ranks(_mpi_recurrent_worker, 2)
+    params, ro = _recurrent_data()
+    _, rets = scan.gae(ro["rewards"], ro["values"], ro["dones"], ro["last_values"], ro["last_dones"], 0.99, 0.95)
+    Es = R_E // 2
+    nbt = (Es // 2) * R_T
+    shards = []
+    for r in range(2):
+        c = slice(r * Es, (r + 1) * Es)
+        flat = {k: scan.sf01(v[:, c]) for k, v in dict(obs=ro["obs"], ret=rets, act=ro["actions"], val=ro["values"],
+                                                       nlp=ro["neglogpacs"], msk=ro["dones"]).items()}
+        flat["adv"] = (flat["ret"] - flat["val"])[:, 0]
+        flat["states"] = ro["states"][c]
+        shards.append(flat)
+    oracle = tfgraph.TrainOracle(params, "lstm", "categorical", tfgraph.LossCfg(0.01, 0.5, 0.5, True))
+    plist = list(oracle.p.values())
+    np.random.seed(5)
+    rows = []
+    for ep in perm.recurrent_minibatch_indices(Es, R_T, nbt, NEP):
+        for envs_mb, fl in ep:
+            gs, ls = [], []
+            for f in shards:        # both ranks draw the same local env order; each evaluates its own envs at the shared parameters
+                ls.append(oracle.train(2.5e-4, 0.1, f["obs"][fl], f["ret"][fl], f["msk"][fl], f["act"][fl], f["val"][fl],
+                                       f["adv"][fl], f["nlp"][fl], states=f["states"][envs_mb], apply=False))
+                gs.append([g.clone() for g in oracle.last_grads.values()])
+            mean_g = [(a + b) / 2 for a, b in zip(*gs)]                      # Allreduce(SUM); /= size  (mpi_adam.py:26-28)
+            clipped, _ = tfgraph.clip_by_global_norm(mean_g, 0.5)
+            oracle.adam.update(plist, clipped, 2.5e-4)
+            rows.append(np.mean(ls, axis=0))
+    want = np.concatenate([p.detach().numpy().ravel() for p in plist])
+    np.testing.assert_allclose(losses, np.mean(rows, axis=0), rtol=1e-4, atol=1e-7)
+    diff = float(np.abs(theta - want).max())
+    print("two ranks, mpi mode, cnn + LSTM: parameter diff vs oracle %.3e" % diff)
+    assert diff <= 1e-5

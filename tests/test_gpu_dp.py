@@ -16,45 +16,74 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 D, A, T, E, B, NEP = 17, 6, 8, 32, 64, 2
+HWC, NACT, NLSTM = (36, 36, 2), 4, 32
+# kind -> (nsteps, nenvs over all ranks, global minibatch size); the image cases take a ragged share per rank
+# (their global minibatches are not split evenly by the permutation)
+SHAPES = {"mlp": (T, E, B), "cnn": (6, 8, 16), "lstm": (6, 8, 2 * 6)}
 
 
-def _data():
-    shapes = tfgraph.mlp_param_shapes(D, (64, 64), A, 1, True, "upstream")
-    params = util.make_params(shapes, 41, pi_scale=0.5, jitter=0.02)
-    ro = util.synthetic_mlp_rollout(np.random.RandomState(42), T, E, D, A, 1, True, params, nlp_noise=0.2)
+def _data(kind="mlp"):
+    Tk, Ek, _ = SHAPES[kind]
+    if kind == "mlp":
+        shapes = tfgraph.mlp_param_shapes(D, (64, 64), A, 1, True, "upstream")
+        params = util.make_params(shapes, 41, pi_scale=0.5, jitter=0.02)
+        ro = util.synthetic_mlp_rollout(np.random.RandomState(42), Tk, Ek, D, A, 1, True, params, nlp_noise=0.2)
+        return params, ro
+    cell = "lstm" if kind == "lstm" else None
+    shapes = tfgraph.cnn_param_shapes(HWC[2], NACT, cell, NLSTM, flat=util.cnn_flat(HWC[0], HWC[1]))
+    params = util.make_params(shapes, 51, pi_scale=0.5, jitter=0.002)
+    rng = np.random.RandomState(52)
+    ro = util.synthetic_cnn_rollout(rng, Tk, Ek, HWC, NACT, params, kind="lstm" if cell else "cnn", nlstm=NLSTM if cell else 0)
+    if cell:
+        ro["states"] = (0.2 * rng.randn(Ek, 2 * NLSTM)).astype(np.float32)
     return params, ro
 
 
-def _run_model(params, ro, e0, e1, comm, mode_seed):
+def _run_model(kind, params, ro, e0, e1, comm, mode_seed, nbatch_train=None):
     from baselines_amd import hip, spaces
     from baselines_amd.ppo2 import policies
     from baselines_amd.ppo2.common_functions import DeviceRollout, Model
+    Tk, _, Bk = SHAPES[kind]
+    Bk = nbatch_train or Bk
     dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
     policies.reset_scopes()
-    model = Model(policy=policies.MlpPolicy64, ob_space=spaces.Box(-1, 1, shape=(D,)), ac_space=spaces.Box(-1, 1, shape=(A,)),
-                  nbatch_act=e1 - e0, nbatch_train=B, nsteps=T, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, comm=comm)
+    if kind == "mlp":
+        model = Model(policy=policies.MlpPolicy64, ob_space=spaces.Box(-1, 1, shape=(D,)), ac_space=spaces.Box(-1, 1, shape=(A,)),
+                      nbatch_act=e1 - e0, nbatch_train=Bk, nsteps=Tk, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, comm=comm)
+        hyper = (3e-4, 0.2)
+    else:
+        class SmallLstm(policies.LstmPolicy):
+            def __init__(self, *a, **k):
+                super().__init__(*a, nlstm=NLSTM, **k)
+        model = Model(policy=SmallLstm if kind == "lstm" else policies.CnnPolicy, ob_space=spaces.Box(0, 255, shape=HWC, dtype=np.uint8),
+                      ac_space=spaces.Discrete(NACT), nbatch_act=e1 - e0, nbatch_train=Bk, nsteps=Tk, ent_coef=0.01, vf_coef=0.5,
+                      max_grad_norm=0.5, upstream_loss=True, comm=comm)
+        hyper = (2.5e-4, 0.1)
     model.arena.set_dict(params)
     sl = lambda a: a[:, e0:e1] if a.ndim >= 2 else a[e0:e1]
-    d = DeviceRollout(T, e1 - e0, dev(sl(ro["obs"])), dev(sl(ro["actions"])), dev(sl(ro["rewards"])), dev(sl(ro["values"])),
-                      dev(sl(ro["neglogpacs"])), dev(sl(ro["dones"])), dev(ro["last_values"][e0:e1]), dev(ro["last_dones"][e0:e1]))
+    d = DeviceRollout(Tk, e1 - e0, dev(sl(ro["obs"])), dev(sl(ro["actions"])), dev(sl(ro["rewards"])), dev(sl(ro["values"])),
+                      dev(sl(ro["neglogpacs"])), dev(sl(ro["dones"])), dev(ro["last_values"][e0:e1]), dev(ro["last_dones"][e0:e1]),
+                      states=dev(ro["states"][e0:e1]) if kind == "lstm" else None)
     d.advs_gae, d.returns, d.advs_ori = hip.gae(d.rewards, d.values, d.dones, d.last_values, d.last_dones, 0.99, 0.95)
-    d.advs = d.advs_ori.reshape(T, e1 - e0)
+    d.advs = d.advs_ori.reshape(Tk, e1 - e0)
     np.random.seed(mode_seed)
-    losses = model.train_on_rollout(3e-4, 0.2, d, NEP, B).cpu().numpy()
+    losses = model.train_on_rollout(hyper[0], hyper[1], d, NEP, Bk).cpu().numpy()
+    hip.take_faults()
     theta = model.arena.theta.cpu().numpy()
+    model.close()
     return losses, theta
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, kind, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from baselines_amd.common.mpi_adam import DataParallel
     comm = DataParallel("global")
-    params, ro = _data()
-    e0, e1 = comm.env_range(E)
-    losses, theta = _run_model(params, ro, e0, e1, comm, 5)
+    params, ro = _data(kind)
+    e0, e1 = comm.env_range(SHAPES[kind][1])
+    losses, theta = _run_model(kind, params, ro, e0, e1, comm, 5)
     assert comm.check_synced(torch.from_numpy(theta).cuda())
     if rank == 0:
         out.put((losses, theta))
@@ -62,20 +91,111 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_reproduce_single_process_update():
+@pytest.mark.parametrize("kind", ["mlp", "cnn", "lstm"])
+def test_two_ranks_reproduce_single_process_update(kind):
+    """"global" mode: both ranks draw the single process's minibatch order over all envs and work on their shares (the
+    ownership filter and the shares' statistics run on the device; the shares of the image cases are ragged); the
+    parameters after two epochs must be the single process's up to summation order.  cnn + LSTM: env-sequence
+    minibatches with one global env order (baselines/ppo2/ppo2.py:124-136)."""
     assert torch.cuda.is_available()
-    params, ro = _data()
-    l1, t1 = _run_model(params, ro, 0, E, None, 5)
-    l2, t2 = util.run_ranks(_worker, 2)
-    np.testing.assert_allclose(l2, l1, rtol=5e-5, atol=1e-7)
-    moved = np.abs(t1 - util.flatten_params(params, type("S", (), {"nparams": t1.size, "vars": _vars()})())).max()
-    assert np.abs(t1 - t2).max() <= 2e-6, np.abs(t1 - t2).max()
+    params, ro = _data(kind)
+    l1, t1 = _run_model(kind, params, ro, 0, SHAPES[kind][1], None, 5)
+    l2, t2 = util.run_ranks(_worker, 2, args=(kind,))
+    np.testing.assert_allclose(l2, l1, rtol=5e-5, atol=2e-7)
+    t0 = util.flatten_params(params, type("S", (), {"nparams": t1.size, "vars": _vars(kind)})())
+    moved = np.abs(t1 - t0).max()
+    assert np.abs(t1 - t2).max() <= (2e-6 if kind == "mlp" else 5e-6), np.abs(t1 - t2).max()
     assert moved > 1e-4
 
 
-def _vars():
+def _vars(kind="mlp"):
     from baselines_amd import _lib, hip
-    return hip.PolicySpec(_lib.POLICY_MLP, _lib.DIST_GAUSSIAN, A, 1, ob_dim=D, hidden=(64, 64), order=_lib.ORDER_UPSTREAM).vars
+    if kind == "mlp":
+        return hip.PolicySpec(_lib.POLICY_MLP, _lib.DIST_GAUSSIAN, A, 1, ob_dim=D, hidden=(64, 64), order=_lib.ORDER_UPSTREAM).vars
+    if kind == "cnn":
+        return hip.PolicySpec(_lib.POLICY_CNN, _lib.DIST_CATEGORICAL, NACT, 1, ob_hwc=HWC).vars
+    return hip.PolicySpec(_lib.POLICY_CNN_LSTM, _lib.DIST_CATEGORICAL, NACT, 1, ob_hwc=HWC, nlstm=NLSTM).vars
+
+
+# ---- the kernels of the global-permutation mode ---------------------------------------------------------
+@pytest.mark.parametrize("Ng,Bg,lo,hi,stride", [(4096, 1024, 1024, 2048, 1024), (6000, 1500, 0, 6000, 1500), (8 * 2048 + 40, 4106, 3000, 3001, 64),
+                                                (40000, 10000, 39000, 40000, 10000), (40000, 10000, 5000, 25000, 4000)])
+def test_ownership_filter_and_share_statistics(Ng, Bg, lo, hi, stride):
+    """ppo2hip_filter_owned_i32 / ppo2hip_adv_stats_owned against NumPy on a random global order: per minibatch the owned
+    entries in list order, re-based; their count; {sum a, sum a^2, n} of the share.  The last case hands over list
+    slots too small for the shares: the fault word says so and the lists are cut, not overrun."""
+    from baselines_amd import hip
+    rng = np.random.RandomState(Ng + lo)
+    order = rng.permutation(Ng).astype(np.int32)
+    nmb = Ng // Bg
+    Tl = 8 if (hi - lo) % 8 == 0 else 1
+    El = (hi - lo) // Tl
+    advs = rng.randn(Tl, El)
+    d_advs = torch.as_tensor(advs).cuda()
+    d_idx = torch.as_tensor(order).cuda()
+    out = torch.full((nmb * stride + 7,), -7, dtype=torch.int32, device="cuda")
+    counts = torch.zeros(nmb, dtype=torch.int32, device="cuda")
+    hip.filter_owned(d_idx, Bg, nmb, lo, hi, out, stride, counts)
+    stats = hip.adv_stats_owned(d_advs, d_idx, Bg, nmb, lo, hi, Tl, El).cpu().numpy()
+    bits = hip.take_faults(raise_on_fault=False)
+    got, cnt = out.cpu().numpy(), counts.cpu().numpy()
+    assert np.all(got[nmb * stride:] == -7)
+    overflow = False
+    for j in range(nmb):
+        mb = order[j * Bg:(j + 1) * Bg]
+        want = mb[(mb >= lo) & (mb < hi)] - lo
+        assert cnt[j] == want.size
+        keep = min(want.size, stride)
+        overflow |= want.size > stride
+        np.testing.assert_array_equal(got[j * stride:j * stride + keep], want[:keep])
+        a = advs.T.ravel()[want]          # env-major flat sample s sits at [s % T, s // T]
+        np.testing.assert_allclose(stats[j], [a.sum(), (a * a).sum(), want.size], rtol=1e-12, atol=1e-12)
+        pad = got[j * stride + keep:min((j + 1) * stride, j * stride + want.size + 64)]
+        assert np.all(pad == 0) or want.size >= stride
+    assert bool(bits) == overflow
+
+
+def test_epoch_over_shares_with_one_owner_equals_epoch_dp():
+    """ppo2hip_ppo_epoch_shares on a one-rank RCCL communicator that owns every sample (shares = whole minibatches)
+    against ppo2hip_ppo_epoch_dp on the same list: bit for bit."""
+    from baselines_amd import hip
+    from baselines_amd.ppo2 import policies
+    params, ro = _data("mlp")
+    results = []
+    for shares in (False, True):
+        from baselines_amd import spaces
+        from baselines_amd.ppo2.common_functions import DeviceRollout, Model
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+        policies.reset_scopes()
+        model = Model(policy=policies.MlpPolicy64, ob_space=spaces.Box(-1, 1, shape=(D,)), ac_space=spaces.Box(-1, 1, shape=(A,)),
+                      nbatch_act=E, nbatch_train=B, nsteps=T, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5)
+        model.arena.set_dict(params)
+        d = DeviceRollout(T, E, dev(ro["obs"]), dev(ro["actions"]), dev(ro["rewards"]), dev(ro["values"]), dev(ro["neglogpacs"]),
+                          dev(ro["dones"]), dev(ro["last_values"]), dev(ro["last_dones"]))
+        _, d.returns, d.advs_ori = hip.gae(d.rewards, d.values, d.dones, d.last_values, d.last_dones, 0.99, 0.95, want_advs=False)
+        d.advs = d.advs_ori.reshape(T, E)
+        rref = hip.RolloutRef(model.spec, d.obs, d.actions, d.returns, d.values, d.neglogpacs, d.advs, T, E)
+        idx = dev(np.random.RandomState(3).permutation(T * E).astype(np.int32))
+        nmb = T * E // B
+        losses = torch.zeros((nmb, 8), device="cuda")
+        comm = hip.NativeComm(hip.NativeComm.unique_id(), 0, 1)
+        if shares:
+            stats = hip.adv_stats_owned(d.advs, idx, B, nmb, 0, T * E, T, E)
+            local, counts = torch.empty(T * E, dtype=torch.int32, device="cuda"), torch.empty(nmb, dtype=torch.int32, device="cuda")
+            hip.filter_owned(idx, B, nmb, 0, T * E, local, B, counts)
+            assert counts.cpu().tolist() == [B] * nmb and torch.equal(local, idx)
+            hip.ppo_epoch_shares(model.spec, model.loss_desc, model.arena.theta, model.grads, model.adam_m, model.adam_v, rref, local,
+                                 B, [B] * nmb, stats, 0.2, 1.0 / B, 3e-4, 1, losses, model._workspace(B), model._adam_scratch,
+                                 max_grad_norm=0.5, comm=comm)
+        else:
+            stats = hip.adv_stats(d.advs, idx, B, nmb, T, E)
+            hip.ppo_epoch(model.spec, model.loss_desc, model.arena.theta, model.grads, model.adam_m, model.adam_v, rref, idx, B,
+                          stats, 0.2, 3e-4, 1, losses, model._workspace(B), model._adam_scratch, max_grad_norm=0.5, comm=comm,
+                          grad_scale=1.0)
+        torch.cuda.synchronize()
+        results.append((model.arena.theta.clone(), losses.clone(), model.adam_v.clone(), stats.clone()))
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
 
 
 # ---- running statistics exchanged over the data-parallel group -----------------------------------------
