@@ -133,7 +133,7 @@ def conv(x_nhwc, p, scope, stride):
     return y.permute(0, 2, 3, 1)
 
 
-def nature_cnn(p, obs_u8, relu_on=None, acts_out=None):
+def nature_cnn(p, obs_u8, relu_on=None, acts_out=None, pre_out=None):
     """``baselines/ppo2/policies.py:6-16``; flatten keeps NHWC order (``conv_to_fc``
     ``baselines/a2c/utils.py:149-152``).
 
@@ -142,11 +142,14 @@ def nature_cnn(p, obs_u8, relu_on=None, acts_out=None):
     implementation and this float64 one disagree about the sign of the few pre-activations that lie within
     float32 rounding of zero (a handful among 10^7), and each such unit opens or closes a whole gradient
     path; with the implementation's own on/off pattern handed in, the two compute the same function.
-    ``acts_out``: optional list that receives the four activations."""
+    ``acts_out``: optional list that receives the four activations; ``pre_out``: one that receives the four
+    pre-activations (the rectifiers' inputs)."""
     dtype = p["c1/w"].dtype
     x = obs_u8.to(dtype) / 255.0
 
     def rect(z, i):
+        if pre_out is not None:
+            pre_out.append(z)
         h = F.relu(z) if relu_on is None else z * torch.as_tensor(relu_on[i]).reshape(z.shape).to(dtype)
         if acts_out is not None:
             acts_out.append(h)
@@ -158,9 +161,9 @@ def nature_cnn(p, obs_u8, relu_on=None, acts_out=None):
     return rect(fc(h, p, "fc1"), 3)
 
 
-def cnn_forward(p, obs_u8, relu_on=None, acts_out=None):
+def cnn_forward(p, obs_u8, relu_on=None, acts_out=None, pre_out=None):
     """``CnnPolicy``, ``baselines/ppo2/policies.py:100-130``; returns (logits, vf[B,1])."""
-    h = nature_cnn(p, obs_u8, relu_on, acts_out)
+    h = nature_cnn(p, obs_u8, relu_on, acts_out, pre_out)
     return fc(h, p, "pi"), fc(h, p, "v")
 
 
@@ -205,9 +208,9 @@ def lstm_forward(p, xs, masks, state, nenv, nsteps, layer_norm=False):
     return hs, torch.cat([c, h], dim=1)
 
 
-def cnn_lstm_forward(p, obs_u8, masks, state, nenv, nsteps, layer_norm=False, relu_on=None, acts_out=None):
+def cnn_lstm_forward(p, obs_u8, masks, state, nenv, nsteps, layer_norm=False, relu_on=None, acts_out=None, pre_out=None):
     """``LstmPolicy`` / ``LnLstmPolicy``, ``baselines/ppo2/policies.py:18-98``."""
-    h = nature_cnn(p, obs_u8, relu_on, acts_out)
+    h = nature_cnn(p, obs_u8, relu_on, acts_out, pre_out)
     h5, snew = lstm_forward(p, h, masks, state, nenv, nsteps, layer_norm)
     return fc(h5, p, "pi"), fc(h5, p, "v"), snew
 
@@ -354,18 +357,19 @@ class TrainOracle:
     def forward(self, obs, masks=None, states=None, relu_on=None):
         p = self.p
         self.last_acts = []     # the rectified activations of the nature_cnn trunk (c1, c2, c3, fc1), when there is one
+        self.last_pre = []      # ... and the rectifiers' inputs
         if self.kind == "mlp":
             pi, vf = mlp_forward(p, torch.as_tensor(obs).to(self.dtype))
             snew = None
         elif self.kind == "cnn":
-            pi, vf = cnn_forward(p, torch.as_tensor(obs), relu_on, self.last_acts)
+            pi, vf = cnn_forward(p, torch.as_tensor(obs), relu_on, self.last_acts, self.last_pre)
             snew = None
         else:
             nenv = states.shape[0]
             pi, vf, snew = cnn_lstm_forward(
                 p, torch.as_tensor(obs), torch.as_tensor(masks).to(self.dtype),
                 torch.as_tensor(states).to(self.dtype), nenv, obs.shape[0] // nenv,
-                layer_norm=(self.kind == "lnlstm"), relu_on=relu_on, acts_out=self.last_acts)
+                layer_norm=(self.kind == "lnlstm"), relu_on=relu_on, acts_out=self.last_acts, pre_out=self.last_pre)
         return pi, vf, snew
 
     def neglogp_entropy(self, pi, actions):

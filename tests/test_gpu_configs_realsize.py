@@ -174,12 +174,16 @@ def test_nature_cnn_minibatch_of_8192(mods):
     # the whole minibatch against the float64 restatement
     rows = _host_rows(ro, idx, T, E)
     oracle = tfgraph.TrainOracle(params, "cnn", "categorical", tfgraph.LossCfg(0.01, 0.5, 0.5, True))
+    # (before the oracle's own optimiser step moves its parameters)
+    nflip = util.check_rectifiers_against_the_oracles_own(oracle, relu_on, acts, rows["obs"])
+    print("nature_cnn minibatch 8192: %d of %d rectified units take the other side of zero in float64" % (nflip, sum(a.size for a in acts)))
     o_losses = oracle.train(2.5e-4, 0.1, rows["obs"], rows["ret"], None, rows["act"], rows["val"],
                             _normalised(rows["adv"], stats.cpu().numpy()[0]), rows["nlp"], normalize=False, relu_on=relu_on)
     _check_activations(oracle, acts)
     np.testing.assert_allclose(full_l, o_losses, rtol=5e-5, atol=1e-7)
     want = np.concatenate([oracle.last_grads[name].numpy().ravel() for name, _, _ in spec.vars])
     _check_grads(spec, full_g, want, "8192 rows vs oracle")
+
     m, v = torch.zeros_like(theta), torch.zeros_like(theta)
     hip.ppo_grad(spec, loss_desc, theta, rref, idx, B, stats, 0.1, 1.0 / B, grads, losses, ws)
     hip.adam_step(theta, grads, m, v, 2.5e-4, 1, hip.adam_scratch(spec.nparams, "cuda"), max_grad_norm=0.5)
@@ -224,6 +228,9 @@ def test_cnn_lstm_full_depth_env_sequences(mods):
     rows = _host_rows(ro, flat, T, E)
     assert rows["masks"].reshape(16, T)[:, 1:].sum() >= 16, "several resets inside these sequences"
     oracle = tfgraph.TrainOracle(params, "lstm", "categorical", tfgraph.LossCfg(0.01, 0.5, 0.5, True))
+    nflip = util.check_rectifiers_against_the_oracles_own(oracle, relu_on, acts, rows["obs"], rows["masks"].astype(bool),
+                                                          ro["states"][envs.long()].cpu().numpy())
+    print("cnn_lstm 16 envs x 128 steps: %d of %d rectified units take the other side of zero in float64" % (nflip, sum(a.size for a in acts)))
     o_losses = oracle.train(2.5e-4, 0.1, rows["obs"], rows["ret"], rows["masks"].astype(bool), rows["act"], rows["val"],
                             _normalised(rows["adv"], stats.cpu().numpy()[0]), rows["nlp"],
                             states=ro["states"][envs.long()].cpu().numpy(), normalize=False, relu_on=relu_on)
@@ -231,6 +238,7 @@ def test_cnn_lstm_full_depth_env_sequences(mods):
     np.testing.assert_allclose(got_l, o_losses, rtol=5e-5, atol=1e-7)
     want = np.concatenate([oracle.last_grads[name].numpy().ravel() for name, _, _ in spec.vars])
     _check_grads(spec, got_g, want, "16 envs x 128 steps vs oracle")
+
     m, v = torch.zeros_like(theta), torch.zeros_like(theta)
     th = theta.clone()
     hip.adam_step(th, grads, m, v, 2.5e-4, 1, hip.adam_scratch(spec.nparams, "cuda"), max_grad_norm=0.5)

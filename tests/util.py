@@ -106,6 +106,29 @@ def synthetic_cnn_rollout(rng, T, E, hwc, nact, params, kind="cnn", nlstm=0, nlp
                 last_values=rng.randn(E, 1).astype(np.float32), last_dones=rng.rand(E) < 0.1, states=states0)
 
 
+def check_rectifiers_against_the_oracles_own(oracle, relu_on, acts, obs, masks=None, states=None):
+    """The pattern handed to the oracle is the product's own, so a unit the kernels wrongly switch OFF would be off on
+    both sides.  Here the float64 restatement runs its forward once more with its OWN rectifiers: the two on/off patterns
+    may differ on fewer than 1e-5 of the units, every unit they differ on must have a float64 pre-activation within 1e-5
+    of zero, and the product's activations must be the oracle's own to 2e-5 — a kernel that zeroes (or invents) live
+    units at its production tiling fails all three."""
+    import torch
+    with torch.no_grad():
+        oracle.forward(obs, masks, states, relu_on=None)
+    for name, on, mine, z, theirs in zip(("c1", "c2", "c3", "fc1"), relu_on, acts, oracle.last_pre, oracle.last_acts):
+        z = z.numpy().reshape(-1)
+        differ = (z > 0) != on.reshape(-1)
+        frac = float(differ.mean())
+        worst = float(np.abs(z[differ]).max()) if differ.any() else 0.0
+        off_here = int(((z > 0) & ~on.reshape(-1)).sum())      # live in float64, off in the pattern under test
+        assert frac < 1e-5, (name, "rectifier patterns differ on %.2e of the units (%d off that float64 has on, %d on that it has "
+                                   "off; largest |pre-activation| among them %.3e)" % (frac, off_here, int(differ.sum()) - off_here, worst))
+        assert worst < 1e-5, (name, "a unit far from zero (%.3e) is on in one pattern and off in the other" % worst)
+        err = float(np.abs(mine.reshape(-1) - theirs.numpy().reshape(-1)).max())
+        assert err <= 2e-5, (name, err)
+    return sum(int(((z.numpy().reshape(-1) > 0) != on.reshape(-1)).sum()) for on, z in zip(relu_on, oracle.last_pre))
+
+
 def free_port():
     import socket
     s = socket.socket()
