@@ -86,6 +86,7 @@ _SIGS = {
     "ppo2hip_perm_begin_relative": (c_int, [c_void_p, c_int, _P]),
     "ppo2hip_compose_i32": (c_int, [_P, _P, _P, c_int64, _P]),
     "ppo2hip_take_faults": (c_int, [ctypes.POINTER(ctypes.c_uint32), _P]),
+    "ppo2hip_post_faults": (c_int, [_P, _P]),
     "ppo2hip_perm_wait": (c_int, [c_void_p, c_int]),
     "ppo2hip_perm_wait_all": (c_int, [c_void_p]),
     "ppo2hip_param_count": (c_int64, [POINTER(PolicyDesc)]),

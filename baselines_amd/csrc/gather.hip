@@ -194,3 +194,16 @@ extern "C" int ppo2hip_take_faults(uint32_t *bits, void *stream) {
     *bits = host;
     return PPO2HIP_OK;
 }
+
+extern "C" int ppo2hip_post_faults(uint32_t *host_bits, void *stream) {
+    using namespace ppo2hip;
+    PPO2HIP_REQUIRE(host_bits != nullptr, "post_faults: null pointer");
+    unsigned *fault = fault_word();
+    if (!fault) return PPO2HIP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(take_faults_kernel, dim3(1), dim3(64), 0, s, fault);
+    int rc = check_launch("take_faults_kernel");
+    if (rc) return rc;
+    PPO2HIP_CHECK_HIP(hipMemcpyAsync(host_bits, fault + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return PPO2HIP_OK;
+}

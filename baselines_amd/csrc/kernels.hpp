@@ -144,6 +144,7 @@ struct AdamFuse {
     unsigned long long *words; // [2 x blocks] per-block sums of squares as tagged halves (workspace of the fused gradient kernel)
     unsigned *fault;          // the device's fault word: a block that gives up waiting raises kFaultGridSync there
     unsigned tag;             // this launch's tag (never zero, never the tag of the launch before on the same workspace)
+    int max_spins;            // polls before a lane gives up (negative: give up at once — a debugging aid, PPO2HIP_GRID_SYNC_SPINS)
 };
 size_t fused_adam_extra_bytes();
 // slabs: nslabs_policy gradient images of the policy trunk, then nslabs_value of the value trunk

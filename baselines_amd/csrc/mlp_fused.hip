@@ -656,6 +656,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(Finaliz
                 constexpr int kMine = kFusedAdamMaxBlocks / 64;
                 unsigned long long hi[kMine], lo[kMine];
                 int spins = 0;
+                if (ad.max_spins < 0) atomicOr(ad.fault, kFaultGridSync);     // debugging aid: behave as if a peer never arrived
                 for (;;) {
                     bool ok = true;
 #pragma unroll
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(64 * kFinGroups) void fused_finalize_kernel(Finaliz
 #pragma unroll
                     for (int u = 0; u < kMine; u++) ok = ok && (unsigned)(hi[u] >> 32) == ad.tag && (unsigned)(lo[u] >> 32) == ad.tag;
                     if (ok) break;
-                    if (++spins > (1 << 20)) {      // never expected; leave rather than hang the device
+                    if (++spins > ad.max_spins) {   // never expected; leave rather than hang the device
                         atomicOr(ad.fault, kFaultGridSync);
                         break;
                     }
@@ -743,6 +744,10 @@ int fused_finalize(const FusedImage &im, const float *slabs, int nslabs_policy, 
         }
         AdamFuse af = *adam;
         af.tag = next_adam_tag();
+        // polls before a waiting lane gives up and raises the grid-sync fault bit; PPO2HIP_GRID_SYNC_SPINS overrides the
+        // limit (negative: every launch raises the bit, which is how the tests exercise the reporting path)
+        static const int spins = getenv("PPO2HIP_GRID_SYNC_SPINS") ? atoi(getenv("PPO2HIP_GRID_SYNC_SPINS")) : (1 << 20);
+        af.max_spins = spins;
         af.fault = fault_word();
         if (!af.fault) return PPO2HIP_EINVAL;
         hipLaunchKernelGGL(fused_finalize_kernel<true>, dim3(fa.nseg_blocks + fa.nhead_blocks + 1), dim3(64 * kFinGroups), 0, s, fa, af);

@@ -405,14 +405,49 @@ def take_faults(raise_on_fault=True):
     bits = ctypes.c_uint32(0)
     check(lib.ppo2hip_take_faults(ctypes.byref(bits), _stream()), "take_faults")
     if bits.value and raise_on_fault:
-        if bits.value & FAULT_GRID_SYNC:
-            raise _lib.Ppo2HipError("a launch whose workgroups hand values to each other (whole-sequence LSTM, or the optimiser step folded "
-                                    "into the epoch call) gave up waiting for its peers (is the GPU shared with another job?); results since "
-                                    "the last check are invalid — PPO2HIP_LSTM_SEQ_OFF=1 takes one LSTM launch per step")
-        what = [name for bit, name in ((FAULT_INDEX_RANGE, "a minibatch index list"), (FAULT_COMPOSE_RANGE, "a permutation handed to compose"))
-                if bits.value & bit]
-        raise _lib.Ppo2HipError("index check failed (code %d): out-of-range entry in %s; results since the last check are invalid" % (_lib.EINVAL, " and ".join(what)))
+        raise fault_error(bits.value)
     return bits.value
+
+
+def fault_error(bits):
+    """The exception a non-zero fault word stands for."""
+    if bits & FAULT_GRID_SYNC:
+        return _lib.Ppo2HipError("a launch whose workgroups hand values to each other (whole-sequence LSTM, or the optimiser step folded "
+                                 "into the epoch call) gave up waiting for its peers (is the GPU shared with another job?); results since "
+                                 "the last check are invalid — PPO2HIP_LSTM_SEQ_OFF=1 takes one LSTM launch per step")
+    what = [name for bit, name in ((FAULT_INDEX_RANGE, "a minibatch index list"), (FAULT_COMPOSE_RANGE, "a permutation handed to compose"))
+            if bits & bit]
+    return _lib.Ppo2HipError("index check failed (code %d): out-of-range entry in %s; results since the last check are invalid"
+                             % (_lib.EINVAL, " and ".join(what)))
+
+
+class FaultWatch:
+    """Fault-word checks that do not stall the stream: ``post()`` queues a read-and-clear of this GPU's fault word behind
+    the work issued so far (the word lands in page-locked memory); ``poll()`` raises for every posted check that has
+    completed with a non-zero word; ``poll(wait=True)`` waits for all of them first."""
+
+    def __init__(self):
+        self._pending = []
+
+    def post(self):
+        host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        check(lib.ppo2hip_post_faults(ctypes.c_void_p(host.data_ptr()), _stream()), "post_faults")
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending.append((ev, host))
+
+    def poll(self, wait=False):
+        keep, bits = [], 0
+        for ev, host in self._pending:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                bits |= int(host.item()) & 0xFFFFFFFF
+            else:
+                keep.append((ev, host))
+        self._pending = keep
+        if bits:
+            raise fault_error(bits)
 
 
 # --------------------------------------------------------------------------------------

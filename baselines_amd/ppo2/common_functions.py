@@ -142,6 +142,7 @@ class Model(object):
         self._ws_rows = 0
         self._stat_ws = None
         self._losses = torch.zeros((1, 8), dtype=torch.float32, device=self.device)
+        self._faults = hip.FaultWatch()
         if comm is not None:
             comm.bcast_(self.arena.theta)          # MpiAdam.sync, baselines/common/mpi_adam.py:37-40
             from . import policies as _policies
@@ -296,7 +297,24 @@ class Model(object):
         shuffle stream (``seed_shuffle``) the next update's index lists are then generated
         ahead, while the GPU works through this one (the shared ``np.random`` stream is never
         drawn from ahead of time: other users of it would see the draws reordered).
+
+        Faults (an index list naming a sample that does not exist, a launch that gave up waiting for its peer
+        workgroups) invalidate the update's results.  A read-and-clear of the GPU's fault word is queued behind every
+        update; this call raises ``Ppo2HipError`` for every earlier update whose check has completed with a non-zero
+        word, and ``check_faults()`` (also run by ``save``) waits for all checks — so a caller that never goes through
+        ``learn`` still cannot keep training on, or save, parameters a faulted launch left behind.
         """
+        self._faults.poll()
+        try:
+            return self._train_on_rollout(lr, cliprange, ro, noptepochs, nbatch_train, events, more_updates)
+        finally:
+            self._faults.post()
+
+    def check_faults(self):
+        """Waits for the fault checks queued behind the updates so far; raises ``Ppo2HipError`` if any launch faulted."""
+        self._faults.poll(wait=True)
+
+    def _train_on_rollout(self, lr, cliprange, ro, noptepochs, nbatch_train, events=None, more_updates=False):
         spec = self.spec
         T, E = ro.T, ro.E
         N = T * E
@@ -604,6 +622,7 @@ class Model(object):
         """joblib list of arrays in variable creation order, written twice
         (baselines/ppo2/common_functions.py:115-119)."""
         import joblib
+        self.check_faults()           # never write out parameters a faulted launch left behind
         ps = self.arena.get_list()
         joblib.dump(ps, save_path)
         if save_path_base is not None:

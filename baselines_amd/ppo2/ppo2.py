@@ -105,7 +105,7 @@ def learn(*, policy, env, nsteps, total_timesteps, ent_coef, lr,
         if device_path:
             lossvals = model.train_on_rollout(float(lrnow), float(cliprangenow), ro, noptepochs, nbatch_train,
                                                more_updates=update < nupdates).cpu().numpy()
-            hip.take_faults()                     # a stale index list raises here, as NumPy's fancy indexing would
+            model.check_faults()                  # a stale index list raises here, as NumPy's fancy indexing would
         else:
             # the reference's host loop (:109-137): shuffle, fancy-index gather, Model.train per minibatch
             advs_host = sf01_host(ro.advs)

@@ -426,7 +426,7 @@ def main():
     dt = max_over_ranks(dt)
     losses = last.cpu().numpy()
     assert np.all(np.isfinite(losses)), "update diverged: %s" % losses
-    hip.take_faults()          # raises if an index list was out of range or a whole-sequence launch gave up a wait
+    model.check_faults()       # raises if an index list was out of range or a launch gave up waiting for its peer workgroups
 
     # instrumented pass: HIP events around the GAE launch and every minibatch gradient evaluation
     events = {"gae": [], "grad": []}
@@ -546,7 +546,7 @@ def main():
                 barrier()
                 xdt = max_over_ranks(time.perf_counter() - t0)
                 xlosses = xlast.cpu().numpy()
-                hip.take_faults()
+                xmodel.check_faults()
                 xev = {"gae": [], "grad": []}
                 xstep(xev)
                 torch.cuda.synchronize()

@@ -196,6 +196,11 @@ int ppo2hip_compose_i32(const int32_t *prev, const int32_t *sigma, int32_t *out,
 #define PPO2HIP_FAULT_GRID_SYNC 4u      /* a launch whose workgroups hand values to each other (whole-sequence LSTM, the
                                          * optimiser step folded into ppo2hip_ppo_epoch) gave up waiting for its peers */
 int ppo2hip_take_faults(uint32_t *bits, void *stream);
+/* The same read-and-clear queued on `stream` WITHOUT waiting: the word lands in *host_bits (page-locked HOST memory that
+ * stays valid until the copy has run; the caller records an event behind this call and reads the word once the event
+ * has completed).  For callers that keep several updates in flight and cannot stall the stream per update; calls on
+ * one stream at a time. */
+int ppo2hip_post_faults(uint32_t *host_bits, void *stream);
 
 /* ------------------------------------------------------------------------
  * Policy description and parameter arena

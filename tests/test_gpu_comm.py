@@ -240,7 +240,7 @@ def _mpi_recurrent_worker(rank, world, port, out):
     d.advs = d.advs_ori.reshape(R_T, Es)
     np.random.seed(5)                       # every rank shuffles its own envs (here: from the same seed)
     losses = model.train_on_rollout(2.5e-4, 0.1, d, NEP, nbt).cpu().numpy()
-    hip.take_faults()
+    model.check_faults()
     assert comm.check_synced(model.arena.theta)
     if rank == 0:
         out.put((losses, model.arena.theta.cpu().numpy()))

@@ -68,7 +68,7 @@ def _run_model(kind, params, ro, e0, e1, comm, mode_seed, nbatch_train=None):
     d.advs = d.advs_ori.reshape(Tk, e1 - e0)
     np.random.seed(mode_seed)
     losses = model.train_on_rollout(hyper[0], hyper[1], d, NEP, Bk).cpu().numpy()
-    hip.take_faults()
+    model.check_faults()
     theta = model.arena.theta.cpu().numpy()
     model.close()
     return losses, theta

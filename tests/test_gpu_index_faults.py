@@ -110,3 +110,69 @@ def test_out_of_range_index_on_image_rollouts_is_reported_not_followed():
             hip.take_faults()
         assert hip.take_faults() == 0
         assert torch.isfinite(grads).all()
+
+
+_DIRECT_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from baselines_amd import _lib, hip, spaces
+from baselines_amd.ppo2 import policies
+from baselines_amd.ppo2.common_functions import DeviceRollout, Model
+D, A, T, E, B = 17, 6, 16, 64, 256
+g = torch.Generator(device="cuda"); g.manual_seed(2)
+f = lambda *s: torch.randn(*s, device="cuda", generator=g)
+model = Model(policy=policies.MlpPolicy64, ob_space=spaces.Box(-1, 1, shape=(D,)), ac_space=spaces.Box(-1, 1, shape=(A,)),
+              nbatch_act=E, nbatch_train=B, nsteps=T, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5)
+d = DeviceRollout(T, E, f(T, E, D), f(T, E, A), f(T, E, 1), f(T, E, 1), f(T, E).abs() + 1.0,
+                  torch.zeros((T, E), dtype=torch.uint8, device="cuda"), f(E, 1), torch.zeros(E, dtype=torch.uint8, device="cuda"))
+_, d.returns, d.advs_ori = hip.gae(d.rewards, d.values, d.dones, d.last_values, d.last_dones, 0.99, 0.95, want_advs=False)
+d.advs = d.advs_ori.reshape(T, E)
+np.random.seed(1)
+out = model.train_on_rollout(3e-4, 0.2, d, 2, B)          # queued; nothing has been waited for yet
+seen = []
+try:
+    model.check_faults()
+except _lib.Ppo2HipError as e:
+    seen.append("check_faults: " + str(e)[:60])
+model.train_on_rollout(3e-4, 0.2, d, 2, B)
+torch.cuda.synchronize()
+try:
+    model.train_on_rollout(3e-4, 0.2, d, 2, B)               # the update before this one faulted: raised on entry
+except _lib.Ppo2HipError as e:
+    seen.append("next update: " + str(e)[:60])
+model.train_on_rollout(3e-4, 0.2, d, 2, B)
+try:
+    model.save(sys.argv[2])
+except _lib.Ppo2HipError as e:
+    seen.append("save: " + str(e)[:60])
+print("SEEN", len(seen), seen)
+"""
+
+
+@pytest.mark.parametrize("forced", [False, True])
+def test_direct_callers_of_train_on_rollout_see_a_faulted_launch(tmp_path, forced):
+    """Model.train_on_rollout outside learn(): the fault word is read behind every update without stalling the stream, and
+    a launch that gave up waiting for its peer workgroups (forced here: PPO2HIP_GRID_SYNC_SPINS=-1 makes the optimiser
+    step folded into the epoch call raise the bit on every launch) surfaces from check_faults(), from the next update's
+    entry and from save() — parameters left by such a launch cannot be trained on or written out unnoticed.  Without the
+    forcing the same calls raise nothing."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "direct.py"
+    script.write_text(_DIRECT_SCRIPT)
+    env = dict(os.environ)
+    if forced:
+        env["PPO2HIP_GRID_SYNC_SPINS"] = "-1"
+    res = subprocess.run([sys.executable, str(script), root, str(tmp_path / "model.pkl")], env=env, capture_output=True, text=True,
+                         timeout=240)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("SEEN")][0]
+    if forced:
+        assert line.startswith("SEEN 3"), line
+        assert "gave up waiting" in line or "hand values" in line
+        assert not os.path.exists(tmp_path / "model.pkl")
+    else:
+        assert line.startswith("SEEN 0"), line
+        assert os.path.exists(tmp_path / "model.pkl")
