@@ -89,6 +89,7 @@ _SIGS = {
     "ppo2hip_post_faults": (c_int, [_P, _P]),
     "ppo2hip_perm_wait": (c_int, [c_void_p, c_int]),
     "ppo2hip_perm_wait_all": (c_int, [c_void_p]),
+    "ppo2hip_perm_wait_drawn": (c_int, [c_void_p]),
     "ppo2hip_param_count": (c_int64, [POINTER(PolicyDesc)]),
     "ppo2hip_param_layout": (c_int, [POINTER(PolicyDesc), c_int, _P, _P, _P]),
     "ppo2hip_forward_workspace_bytes": (c_size_t, [POINTER(PolicyDesc), c_int64]),

@@ -30,6 +30,20 @@ unsigned *fault_word() {
     return g_fault_ptr[dev];
 }
 
+// Compute units of the current device (cached per device): what a launch whose workgroups wait for each other may count
+// on being resident together.  0 when the query fails.
+int device_cu_count() {
+    static int cached[64];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 // one 4-byte (or 1-byte) word of one observation row per loop trip
 template <class W>
 __global__ void gather_rows_kernel(const W *__restrict__ src, const int32_t *__restrict__ idx, int64_t B,
@@ -159,6 +173,11 @@ namespace ppo2hip {
 __global__ void take_faults_kernel(unsigned *words) {
     if (threadIdx.x == 0 && blockIdx.x == 0) words[1] = atomicExch(&words[0], 0u);
 }
+// the same exchange with the result stored straight into page-locked host memory (no copy call on the host's side)
+__global__ void post_faults_kernel(unsigned *words, unsigned *host_bits) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        __hip_atomic_store(host_bits, atomicExch(&words[0], 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void compose_kernel(const int32_t *__restrict__ prev, const int32_t *__restrict__ sigma,
                                int32_t *__restrict__ out, int64_t n, unsigned *fault) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -201,9 +220,6 @@ extern "C" int ppo2hip_post_faults(uint32_t *host_bits, void *stream) {
     unsigned *fault = fault_word();
     if (!fault) return PPO2HIP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(take_faults_kernel, dim3(1), dim3(64), 0, s, fault);
-    int rc = check_launch("take_faults_kernel");
-    if (rc) return rc;
-    PPO2HIP_CHECK_HIP(hipMemcpyAsync(host_bits, fault + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    return PPO2HIP_OK;
+    hipLaunchKernelGGL(post_faults_kernel, dim3(1), dim3(64), 0, s, fault, host_bits);
+    return check_launch("post_faults_kernel");
 }

@@ -74,6 +74,8 @@ int64_t conv_dgrad_colsum_rows(const ConvShape &c);
 // device address of this GPU's fault word (a static device array of the library; symbol lookup on the first call per
 // device, no allocation); null with an error set when the lookup fails
 unsigned *fault_word();
+// compute units of the current device (0 if unknown): the bound for launches whose workgroups wait for each other
+int device_cu_count();
 // how many samples an index into a rollout may name
 inline int64_t rollout_samples(const ppo2hip_rollout &ro) { return ro.T > 0 ? (int64_t)ro.T * ro.E : ro.n; }
 

@@ -373,10 +373,13 @@ static int launch_seq_fwd(const LstmSeqFwd &a, hipStream_t s) {
     return check_launch("lstm_seq_fwd_kernel");
 }
 
-// the whole-sequence kernels need all their workgroups resident at once: one per CU is what they may count on
+// the whole-sequence kernels need all their workgroups resident at once: one per CU of THIS device is what they may
+// count on (a partitioned or smaller GPU takes the per-step launches instead)
 bool lstm_seq_ok(int nenv, int nh) {
     static const bool off = getenv("PPO2HIP_LSTM_SEQ_OFF") != nullptr;
-    return !off && (nh == 64 || nh == 128 || nh == 256 || nh == 512) && (int64_t)(nh / 16) * ceil_div(nenv, 16) <= 256;
+    const int cus = device_cu_count();
+    return !off && (nh == 64 || nh == 128 || nh == 256 || nh == 512) &&
+           (int64_t)(nh / 16) * ceil_div(nenv, 16) <= (cus < 256 ? cus : 256);
 }
 size_t lstm_seq_xchg_bytes(int nenv, int nh) { return (size_t)2 * (nh / 16) * nenv * nh * sizeof(unsigned long long); }
 

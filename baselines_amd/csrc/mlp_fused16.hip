@@ -32,7 +32,11 @@
 namespace ppo2hip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// 16 x 16 x 32 product of bf16 operands (eight per lane and operand, k = 8 lk .. 8 lk + 7), float32 accumulate
+#define MFMA32B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
 namespace f16 {
 constexpr int kThreads = 512;
@@ -41,9 +45,12 @@ constexpr int H = 64;             // both hidden widths
 constexpr int HB = H / 16;        // 16-unit blocks
 // weights (floats)
 constexpr int W1P = 0;                         // [32 inputs][16 li][4 mb]    unit = 16 mb + li; row D = bias
-constexpr int W2P = W1P + 32 * H;              // [16 k4][64 out][4 r]        input unit = 4 k4 + r
-constexpr int W2TP = W2P + H * H;              // [16 j4][64 in][4 r]         output unit = 4 j4 + r
-constexpr int B2 = W2TP + H * H;               // [64]
+// layer 2's weights as bf16 pieces (three per weight, see cut8) in the A-operand order of the 16 x 16 x 32 product:
+// [k-step q (2)][16-row block (4)][piece (3)][lane (64)] x 8 bf16; slot s of lane quarter lk stands for contraction
+// unit 32 q + 4 lk + s (s < 4) or 32 q + 16 + 4 lk + (s - 4): what the lane holds of two adjacent accumulator blocks
+constexpr int W2Q = W1P + 32 * H;              // forward:  rows = output units, contraction over input units (scaled for tanh)
+constexpr int W2TQ = W2Q + 2 * 4 * 3 * 64 * 4; // backward: rows = input units, contraction over output units
+constexpr int B2 = W2TQ + 2 * 4 * 3 * 64 * 4;  // [64]
 constexpr int WHP = B2 + H;                    // [16 k4][16 rows][4 r]       accumulator row -> output (row >> 2) + 4 (row & 3)
 constexpr int WHTP = WHP + H * 16;             // [4 lk][64 units][4 r]       output = lk + 4 r
 constexpr int BHP = WHTP + H * 16;             // [16 rows]
@@ -65,7 +72,7 @@ constexpr int S_WH = S_B2 + H;
 constexpr int S_BH = S_WH + H * 16;
 constexpr int SLAB = S_BH + 16;
 static_assert(4 * SLAB <= TOTAL, "LDS must hold four gradient images for the cross-wave reduction");
-static_assert(TOTAL * 4 + 4096 <= 160 * 1024, "LDS budget");
+static_assert(TOTAL * 4 + 1024 <= 160 * 1024, "LDS budget");
 constexpr int kLossStride = 8 + 64;
 constexpr int kLossVals = 5;
 }  // namespace f16
@@ -114,6 +121,44 @@ __device__ __forceinline__ f32x4 tanh_prescaled4(f32x4 z) {
 // accumulated negated and has its sign put right when the images are written out.
 __device__ __forceinline__ f32x4 neg_times_tanh_grad4(f32x4 dz, f32x4 t) { return dz * (t * t - 1.0f); }
 
+// A float32 is the exact sum of three bf16 numbers: its 24 significand bits cut into runs of eight by truncation
+// (x = hi + mid + lo, each piece what truncating the remainder to bf16 leaves).  Layer 2's two 64 x 64 products per
+// tile run on the bf16 matrix pipe from such pieces: weights cut once per launch, activations per tile.  Of the nine
+// piece products the six whose weight is 2^-16 of the result or more are kept (hi hi, hi mid, mid hi, hi lo, lo hi,
+// mid mid): every kept product is exact in the float32 accumulator, what is dropped is below 2^-24 of the term it
+// belongs to — the rounding class of the float32 fma chain itself — and the bf16 pipe retires the 64-deep contraction
+// in 2 x 6 instructions of 16 cycles where the float32 form takes 16 of 32.
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {        // the bf16 truncations of a (low half) and b (high half)
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ void cut8(const f32x4 &v0, const f32x4 &v1, uint4 &hi, uint4 &mid, uint4 &lo) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const f32x4 &v = d < 2 ? v0 : v1;
+        const f32x2 x = {v[2 * (d & 1)], v[2 * (d & 1) + 1]};
+        const f32x2 xh = {__uint_as_float(__float_as_uint(x[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(x[1]) & 0xffff0000u)};
+        const f32x2 r1 = x - xh;                                          // exact: the low sixteen significand bits
+        const f32x2 rh = {__uint_as_float(__float_as_uint(r1[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(r1[1]) & 0xffff0000u)};
+        const f32x2 r2 = r1 - rh;                                         // exact: at most eight bits, a bf16 as it stands
+        h[d] = pack_hi16(x[0], x[1]);
+        m[d] = pack_hi16(r1[0], r1[1]);
+        l[d] = pack_hi16(r2[0], r2[1]);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    mid = make_uint4(m[0], m[1], m[2], m[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// acc[m] += A_q,m x B over the six kept piece products, small ones first; the blocks' accumulators take turns so that
+// consecutive instructions do not depend on each other
+#define PIECE_PRODUCTS(acc, m0, a, b, NB)                                               \
+    {                                                                                   \
+        constexpr int pa_[6] = {2, 0, 1, 1, 0, 0}, pb_[6] = {0, 2, 1, 0, 1, 0};         \
+        _Pragma("unroll") for (int t_ = 0; t_ < 6; t_++)                                \
+            _Pragma("unroll") for (int m_ = 0; m_ < NB; m_++)                           \
+                acc[(m0) + m_] = MFMA32B(a[m_][pa_[t_]], b[pb_[t_]], acc[(m0) + m_]);   \
+    }
+
 // KQ = k-steps of layer 1 (ob_dim + 1 <= 4 KQ; also the observation registers per lane);
 // WIDE = ob_dim + 1 > 16 with the second block of dW1 rows as matrix products;
 // XV = 1 or 2: ob_dim = 15 + XV, the one or two feature rows past the first sixteen (x16 if any, and the ones row)
@@ -125,7 +170,9 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
     __shared__ __attribute__((aligned(16))) float lds[TOTAL];
     __shared__ double red[kWaves * kLossVals];
 #define LDS4(off) (*(const f32x4 *)(lds + (off)))
+#define LDSQ(base, q, m, p) (*(const uint4 *)(lds + (base) + 4 * ((((q) * 4 + (m)) * 3 + (p)) * 64 + lane)))
 
+    constexpr int PB = WIDE ? 1 : 2;      // accumulator blocks a piece product serves at a time (register budget)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const bool is_value = (int)blockIdx.x >= g.nwg_policy;
@@ -198,13 +245,33 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
             const float v = k <= D ? P[o_w1 + (int64_t)k * H + j] : 0.f;   // rows 0..D-1 weights, row D = bias
             lds[W1P + k * 64 + (j & 15) * 4 + (j >> 4)] = kTanhScale * v;  // forward copy: pre-activations arrive scaled for tanh
         }
+        {
+            unsigned short *const fq = (unsigned short *)(lds + W2Q), *const bq = (unsigned short *)(lds + W2TQ);
+            // where contraction unit c (0..63) sits: k-step, lane quarter, slot
+            auto slot = [](int c, int &q, int &lq, int &sl) { q = c >> 5; lq = (c & 15) >> 2; sl = (c & 3) + ((c >> 4) & 1) * 4; };
+            auto cut = [](float x, unsigned short (&pc)[3]) {
+                const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+                const float r1 = x - __uint_as_float(hb);
+                const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+                const float r2 = r1 - __uint_as_float(mb);
+                pc[0] = (unsigned short)(hb >> 16); pc[1] = (unsigned short)(mb >> 16); pc[2] = (unsigned short)(__float_as_uint(r2) >> 16);
+            };
 #pragma unroll
-        for (int u = 0; u < H * H / kThreads; u++) {
-            const int e = tid + u * kThreads;
-            const int k = e >> 6, j = e & 63;
-            const float v = P[o_w2 + e];
-            lds[W2P + ((k >> 2) * 64 + j) * 4 + (k & 3)] = kTanhScale * v;     // forward copy (scaled), backward copy (as is)
-            lds[W2TP + ((j >> 2) * 64 + k) * 4 + (j & 3)] = v;
+            for (int u = 0; u < H * H / kThreads; u++) {
+                const int e = tid + u * kThreads;
+                const int k = e >> 6, j = e & 63;                              // W2[input unit k][output unit j] (coalesced read)
+                const float v = P[o_w2 + e];
+                unsigned short pc[3];
+                int q, lq, sl;
+                cut(kTanhScale * v, pc);                                       // forward copy: pre-activations arrive scaled for tanh
+                slot(k, q, lq, sl);
+#pragma unroll
+                for (int p = 0; p < 3; p++) fq[((((q * 4 + (j >> 4)) * 3 + p) * 64) + lq * 16 + (j & 15)) * 8 + sl] = pc[p];
+                cut(v, pc);                                                    // backward copy
+                slot(j, q, lq, sl);
+#pragma unroll
+                for (int p = 0; p < 3; p++) bq[((((q * 4 + (k >> 4)) * 3 + p) * 64) + lq * 16 + (k & 15)) * 8 + sl] = pc[p];
+            }
         }
         if (tid < H) lds[B2 + tid] = kTanhScale * P[o_w2 + (int64_t)H * H + tid];
 #pragma unroll
@@ -369,22 +436,21 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
 
         // ---- layer 2: h2 = tanh(W2^T h1 + b2); the bias seeds the accumulator ------------------------
         {
-            f32x4 w[2][HB];
 #pragma unroll
-            for (int m = 0; m < HB; m++) {
-                h2[m] = LDS4(B2 + 16 * m + 4 * lk);
-                w[0][m] = LDS4(W2P + wpos + 64 * m);
-            }
+            for (int m = 0; m < HB; m++) h2[m] = LDS4(B2 + 16 * m + 4 * lk);
 #pragma unroll
-            for (int mb = 0; mb < HB; mb++) {
-                if (mb + 1 < HB) {
+            for (int q = 0; q < 2; q++) {
+                uint4 b[3];
+                cut8(h1[2 * q], h1[2 * q + 1], b[0], b[1], b[2]);
 #pragma unroll
-                    for (int m = 0; m < HB; m++) w[(mb + 1) & 1][m] = LDS4(W2P + wpos + 1024 * (mb + 1) + 64 * m);
+                for (int m0 = 0; m0 < HB; m0 += PB) {        // PB output blocks at a time: 12 PB operand registers, not 48
+                    uint4 a[PB][3];
+#pragma unroll
+                    for (int m = 0; m < PB; m++)
+#pragma unroll
+                        for (int p = 0; p < 3; p++) a[m][p] = LDSQ(W2Q, q, m0 + m, p);
+                    PIECE_PRODUCTS(h2, m0, a, b, PB)
                 }
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int m = 0; m < HB; m++) h2[m] = MFMA16(w[mb & 1][m][r], h1[mb][r], h2[m]);
             }
         }
 #pragma unroll
@@ -586,23 +652,23 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
         // ---- layer 2: input gradient first (dz2 is still in registers) ------------------------------------
         f32x4 dz1[HB];
         {
-            f32x4 wt[2][HB];
-#pragma unroll
-            for (int mb = 0; mb < HB; mb++) wt[0][mb] = LDS4(W2TP + wpos + 64 * mb);
 #pragma unroll
             for (int mb = 0; mb < HB; mb++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) dz1[mb][r] = 0.f;
 #pragma unroll
-            for (int m = 0; m < HB; m++) {
-                if (m + 1 < HB) {
+            for (int q = 0; q < 2; q++) {
+                uint4 b[3];
+                cut8(dz2[2 * q], dz2[2 * q + 1], b[0], b[1], b[2]);
 #pragma unroll
-                    for (int mb = 0; mb < HB; mb++) wt[(m + 1) & 1][mb] = LDS4(W2TP + wpos + 1024 * (m + 1) + 64 * mb);
+                for (int m0 = 0; m0 < HB; m0 += PB) {
+                    uint4 a[PB][3];
+#pragma unroll
+                    for (int mb = 0; mb < PB; mb++)
+#pragma unroll
+                        for (int p = 0; p < 3; p++) a[mb][p] = LDSQ(W2TQ, q, m0 + mb, p);
+                    PIECE_PRODUCTS(dz1, m0, a, b, PB)
                 }
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int mb = 0; mb < HB; mb++) dz1[mb] = MFMA16(wt[m & 1][mb][r], dz2[m][r], dz1[mb]);
             }
         }
 #pragma unroll
@@ -768,6 +834,7 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
         g.loss_partial[(int64_t)blockIdx.x * kLossStride + tid] = v;
     }
 #undef LDS4
+#undef LDSQ
 }
 
 bool mlp_fused16_supported(const ppo2hip_policy_desc &d) {

@@ -235,7 +235,8 @@ static int mlp_grad(const ppo2hip_policy_desc &d, const ppo2hip_loss_desc &lc, c
                         L.off("vf/w"), gauss ? L.off("logstd") : 0};
         if (path == 16) {
             // the optimiser step rides in the finalize launch when the caller offers it and the arena is small enough
-            const bool fold = adam && L.total <= 16384 && !(getenv("PPO2HIP_NO_FUSED_ADAM"));
+            // (its blocks, one per 64 parameters plus the head and loss blocks, wait for each other: one per CU of this device)
+            const bool fold = adam && L.total <= 16384 && device_cu_count() >= (L.total + 63) / 64 + 8 && !(getenv("PPO2HIP_NO_FUSED_ADAM"));
             if (fold && adam_done) *adam_done = true;
             return mlp_fused16_grad(d, lc, p, fo, ro, idx, B, stats, cliprange, inv_count, grads, losses, w.fused,
                                     w.fused_bytes, s, fold ? adam : nullptr);

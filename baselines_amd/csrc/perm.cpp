@@ -489,6 +489,16 @@ extern "C" int ppo2hip_perm_wait(ppo2hip_perm *p, int epoch) {
     return PPO2HIP_OK;
 }
 
+extern "C" int ppo2hip_perm_wait_drawn(ppo2hip_perm *p) {
+    if (!p) {
+        ppo2hip::set_error("perm_wait_drawn: null handle");
+        return PPO2HIP_EINVAL;
+    }
+    // every epoch of the job has drawn its swap targets: the generator is free, although swaps may still be running
+    p->await([&] { return p->nepochs == 0 || p->epochs_drawn.load(std::memory_order_acquire) >= p->nepochs; }, p->spin_stage_us);
+    return PPO2HIP_OK;
+}
+
 extern "C" int ppo2hip_perm_wait_all(ppo2hip_perm *p) {
     if (!p) {
         ppo2hip::set_error("perm_wait_all: null handle");

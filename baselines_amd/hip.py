@@ -382,6 +382,10 @@ class PermPipeline:
     def wait_all(self):
         check(lib.ppo2hip_perm_wait_all(self._h), "perm_wait_all")
 
+    def wait_drawn(self):
+        """Blocks until the running job has drawn all its swap targets (the generator is free for another pipeline)."""
+        check(lib.ppo2hip_perm_wait_drawn(self._h), "perm_wait_drawn")
+
 
 def compose(prev, sigma, out):
     """out[k] = prev[sigma[k]] on the device (int32): the minibatch order after one more shuffle."""
@@ -426,11 +430,20 @@ class FaultWatch:
     the work issued so far (the word lands in page-locked memory); ``poll()`` raises for every posted check that has
     completed with a non-zero word; ``poll(wait=True)`` waits for all of them first."""
 
+    SLOTS = 64
+
     def __init__(self):
         self._pending = []
+        self._ring = None        # page-locked words the one-thread kernel stores into, used in turn
+        self._next = 0
 
     def post(self):
-        host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        if self._ring is None:
+            self._ring = torch.zeros(self.SLOTS, dtype=torch.int32, pin_memory=True)
+        if len(self._pending) >= self.SLOTS - 1:
+            self.poll(wait=True)                    # never more checks in flight than words to hold them
+        host = self._ring[self._next:self._next + 1]
+        self._next = (self._next + 1) % self.SLOTS
         check(lib.ppo2hip_post_faults(ctypes.c_void_p(host.data_ptr()), _stream()), "post_faults")
         ev = torch.cuda.Event()
         ev.record()

@@ -33,40 +33,105 @@ class DeviceRollout:
 
 
 class _IndexUploader:
-    """Moves an index job's lists from the pipeline's page-locked buffers to HBM on a thread and a stream of its own, as
-    the lists are finished, normally an update ahead of their use.  hipMemcpyAsync from page-locked memory now and then
-    holds its calling thread for 3-6 ms (the runtime call itself: torch's copy_ and a bare call alike); on the thread that
-    feeds the GPU that is one update in ten taking 5 ms instead of 1.8.  Here it only delays a copy nobody is waiting for
-    yet.  ``stage[s][e]`` receives epoch e of the job in buffer set s; ``ready`` is the event after its copy, ``free``
-    the event (set by the consumer) after which the staging buffer may be overwritten."""
+    """Index lists of successive updates, from the permutation pipelines' page-locked buffers to HBM, off the thread
+    that feeds the GPU.
 
-    def __init__(self, device, pp, n, nepochs):
+    Two pipelines on ONE generator take the updates' jobs in turn (job k: pipeline and buffer set k % 2).  A scheduler
+    thread begins job k as soon as (i) the caller has asked for it (``request``), (ii) job k - 1 has drawn all its swap
+    targets — the generator is free, although that job's last swaps still run, so consecutive jobs overlap and the
+    period is the serial draw time, not the job time — and (iii) the caller has finished queueing update k - 2, whose
+    buffers job k reuses.  An uploader thread with a stream of its own copies each list into a staging buffer as the
+    pipeline finishes it.  hipMemcpyAsync from page-locked memory now and then holds its calling thread for 3-6 ms (the
+    runtime call itself: torch's copy_ and a bare call alike); here that only delays a copy nobody is waiting for yet.
+    ``stage[s][e]`` receives epoch e of the job in set s; ``ready`` is the event after its copy, ``free`` the event (set
+    by the consumer) after which the staging buffer may be overwritten."""
+
+    def __init__(self, device, pps, n, nepochs):
         import queue
         import threading
-        self.device, self.pp = device, pp
+        self.device, self.pps, self.nepochs = device, pps, nepochs
         self.stream = torch.cuda.Stream(device=device)
-        nsets = len(pp.sets)
+        nsets = len(pps)
         self.stage = [[torch.empty(n, dtype=torch.int32, device=device) for _ in range(nepochs)] for _ in range(nsets)]
         self.ready = [[None] * nepochs for _ in range(nsets)]
         self.free = [[None] * nepochs for _ in range(nsets)]
         self.issued = [[threading.Event() for _ in range(nepochs)] for _ in range(nsets)]
+        self.last_copy = [None] * nsets          # event behind the last copy out of each set's page-locked buffers
         self.error = None
+        self.cv = threading.Condition()
+        self.jobs_wanted = 0                     # jobs the caller has asked for
+        self.jobs_begun = 0                      # jobs handed to a pipeline
+        self.jobs_used = 0                       # updates the caller has finished queueing
+        self.quit = False
         self._jobs = queue.Queue()
         self._thread = threading.Thread(target=self._run, name="ppo2hip-index-upload", daemon=True)
+        self._sched = threading.Thread(target=self._schedule, name="ppo2hip-index-schedule", daemon=True)
         self._thread.start()
+        self._sched.start()
 
-    def submit(self, s, nepochs):
-        for e in range(nepochs):
-            self.issued[s][e].clear()
-        self._jobs.put((s, nepochs))
+    # ---- caller's side ------------------------------------------------------------------
+    def request(self, upto):
+        """Jobs 0 .. upto - 1 are to be generated (each as soon as the conditions above allow)."""
+        with self.cv:
+            if upto > self.jobs_wanted:
+                self.jobs_wanted = upto
+                self.cv.notify_all()
+
+    def consumed(self, k):
+        """Update k has been queued in full: its buffer set may be reused by job k + 2."""
+        with self.cv:
+            self.jobs_used = max(self.jobs_used, k + 1)
+            self.cv.notify_all()
+
+    def wait(self, s, e):
+        """(device list, event after its copy) of epoch e of the job in set s; blocks until the copy has been issued."""
+        self.issued[s][e].wait()
+        if self.error is not None:
+            raise self.error
+        return self.stage[s][e], self.ready[s][e]
 
     def close(self, timeout=10.0):
-        """Ends the thread (after the jobs already queued) and waits for it, so that it is not inside a HIP call when the
-        interpreter or its owner goes away; the staging buffers are released with the object."""
+        """Ends both threads (after the jobs already begun) and waits for them, so that neither is inside a HIP call
+        when the interpreter or its owner goes away; the staging buffers are released with the object."""
         if self._thread is not None:
+            with self.cv:
+                self.quit = True
+                self.cv.notify_all()
+            self._sched.join(timeout)
             self._jobs.put(None)
             self._thread.join(timeout)
-            self._thread = None
+            self._thread = self._sched = None
+
+    # ---- threads -------------------------------------------------------------------------
+    def _schedule(self):
+        torch.cuda.set_device(self.device)
+        try:
+            while True:
+                with self.cv:
+                    self.cv.wait_for(lambda: self.quit or (self.jobs_begun < self.jobs_wanted and self.jobs_used >= self.jobs_begun - 1))
+                    if self.quit:
+                        return
+                    k = self.jobs_begun
+                s = k % len(self.pps)
+                if k >= 1:
+                    self.pps[(k - 1) % len(self.pps)].wait_drawn()     # the generator has moved past job k - 1 (no GIL held)
+                if self.last_copy[s] is not None:
+                    self.last_copy[s].synchronize()                   # copies out of this set (two jobs ago) have run
+                for e in range(self.nepochs):
+                    self.issued[s][e].clear()
+                self.pps[s].begin(self.nepochs, relative=True)
+                self._jobs.put((s, self.nepochs))
+                with self.cv:
+                    self.jobs_begun = k + 1
+                    self.cv.notify_all()
+        except BaseException as ex:          # hand the failure to the thread that waits
+            self._fail(ex)
+
+    def _fail(self, ex):
+        self.error = ex
+        for row in self.issued:
+            for ev in row:
+                ev.set()
 
     def _run(self):
         torch.cuda.set_device(self.device)
@@ -77,26 +142,19 @@ class _IndexUploader:
             s, nepochs = job
             try:
                 for e in range(nepochs):
-                    hip.check(_lib.lib.ppo2hip_perm_wait(self.pp._h, e), "perm_wait")      # blocks without the GIL
+                    hip.check(_lib.lib.ppo2hip_perm_wait(self.pps[s]._h, e), "perm_wait")      # blocks without the GIL
                     with torch.cuda.stream(self.stream):
                         if self.free[s][e] is not None:
                             self.stream.wait_event(self.free[s][e])
-                        self.stage[s][e].copy_(self.pp.sets[s][e], non_blocking=True)
+                        self.stage[s][e].copy_(self.pps[s].bufs[e], non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(self.stream)
                     self.ready[s][e] = ev
+                    if e == nepochs - 1:
+                        self.last_copy[s] = ev
                     self.issued[s][e].set()
-            except BaseException as ex:      # hand the failure to the thread that waits
-                self.error = ex
-                for e in range(nepochs):
-                    self.issued[s][e].set()
-
-    def wait(self, s, e):
-        """(device list, event after its copy) of epoch e of the job in set s; blocks until the copy has been issued."""
-        self.issued[s][e].wait()
-        if self.error is not None:
-            raise self.error
-        return self.stage[s][e], self.ready[s][e]
+            except BaseException as ex:
+                self._fail(ex)
 
 
 class Model(object):
@@ -243,6 +301,7 @@ class Model(object):
         """Give the model its own MT19937 stream for minibatch shuffles (same stream as
         ``np.random.seed(seed)``); without it the global ``np.random`` stream is used, as in
         the reference."""
+        self.close()                       # lists generated ahead from an earlier stream are dropped with their pipelines
         self._shuffler = hip.LegacyShuffler(seed)
         self._own_stream = True
 
@@ -252,34 +311,40 @@ class Model(object):
             if not hasattr(self, "_shuffler"):
                 self._shuffler = hip.LegacyShuffler(0)
                 self._own_stream = False
-            self._pp = hip.PermPipeline(self._shuffler, N, noptepochs, nsets=2)
-            self._pp_key = key
-            self._pp_set = 0               # buffer set of the job in flight / last used
-            self._pp_ahead = False         # a job for the coming update is already running
-            self._set_copied = [None, None]   # last copy event out of each buffer set
-            self._idx_dev = [torch.empty(N, dtype=torch.int32, device=self.device) for _ in range(noptepochs)]
             if getattr(self, "_uploader", None) is not None:
-                self._uploader.close()
-                self._uploader_finalizer.detach()
-            self._uploader = _IndexUploader(self.device, self._pp, N, noptepochs)
-            # the uploader's thread and staging buffers go with the model: the thread references the uploader only
+                self._uploader_finalizer()
+            # two pipelines on the one generator: consecutive updates' jobs overlap (see _IndexUploader)
+            self._pps = [hip.PermPipeline(self._shuffler, N, noptepochs, nsets=1) for _ in range(2)]
+            self._pp_key = key
+            self._job = 0                  # number of the job (= update with this shape) the next call consumes
+            self._idx_dev = [torch.empty(N, dtype=torch.int32, device=self.device) for _ in range(noptepochs)]
+            self._uploader = _IndexUploader(self.device, self._pps, N, noptepochs)
+            # the uploader's threads and staging buffers go with the model: the threads reference the uploader only
             import weakref
             self._uploader_finalizer = weakref.finalize(self, self._uploader.close)
             self._idx_free = [None] * noptepochs      # main-stream event: kernels reading _idx_dev[e] done
             self._copy_stream = torch.cuda.Stream(device=self.device)
             self._side_stats = [None] * noptepochs    # per epoch: (workspace, out) of the advantage statistics taken on the side stream
-        return self._pp
+        return self._uploader
 
-    def _begin_index_job(self, pp, noptepochs):
-        """Start generating an update's index lists into the buffer set not used by the last job."""
-        s = self._pp_set ^ 1
-        if self._set_copied[s] is not None:
-            self._set_copied[s].synchronize()      # copies out of that set (two jobs ago) have run
+    def _open_index_job(self, more_updates):
+        """This update's job (and, when the model owns its shuffle stream and another update follows, the next one's:
+        it is generated while the GPU works through this update) -> (job number, its buffer set)."""
+        up, k = self._uploader, self._job
         if not self._own_stream:
+            # the shared np.random stream is never drawn from ahead of time: other users of it would see the draws reordered
             self._shuffler.adopt_numpy()
-        pp.begin(noptepochs, relative=True, buffer_set=s)
-        self._pp_set = s
-        self._uploader.submit(s, noptepochs)
+            up.request(k + 1)
+        else:
+            up.request(k + 2 if more_updates else k + 1)
+        return k, k % 2
+
+    def _close_index_job(self, k):
+        if not self._own_stream:
+            self._pps[k % 2].wait_all()
+            self._shuffler.release_numpy()
+        self._uploader.consumed(k)
+        self._job = k + 1
 
     def train_on_rollout(self, lr, cliprange, ro, noptepochs, nbatch_train, events=None, more_updates=False):
         """All epochs x minibatches of one update from device-resident rollout buffers.
@@ -333,10 +398,8 @@ class Model(object):
             if N % nbatch_train != 0:
                 raise AssertionError("nbatch %% nbatch_train != 0")   # baselines/ppo2/ppo2.py:74
             nmb = N // nbatch_train
-            pp = self._index_pipeline(N, noptepochs)
-            if not self._pp_ahead:
-                self._begin_index_job(pp, noptepochs)
-            self._pp_ahead = False
+            self._index_pipeline(N, noptepochs)
+            job, pset = self._open_index_job(more_updates)
         else:
             envsperbatch = nbatch_train // T
             if envsperbatch < 1 or E % envsperbatch != 0:
@@ -361,7 +424,7 @@ class Model(object):
             stats = None
             if not spec.recurrent:
                 # this epoch's own permutation of arange(N), uploaded by the side thread (normally long since)
-                sig, sig_ready = self._uploader.wait(self._pp_set, e)
+                sig, sig_ready = self._uploader.wait(pset, e)
                 d_idx = sig if e == 0 else self._idx_dev[e]
                 with torch.cuda.stream(self._copy_stream):
                     self._copy_stream.wait_event(sig_ready)
@@ -381,7 +444,6 @@ class Model(object):
                     ev = torch.cuda.Event()
                     ev.record(self._copy_stream)
                 d_prev = d_idx
-                self._set_copied[self._pp_set] = sig_ready        # uploads run in order: the last one's event covers the set
                 main.wait_event(ev)
                 d_envs = None
             else:
@@ -405,7 +467,7 @@ class Model(object):
                 done = torch.cuda.Event()
                 done.record(main)
                 self._idx_free[e] = done
-                self._uploader.free[self._pp_set][e] = done
+                self._uploader.free[pset][e] = done
                 continue
             for j in range(nmb):
                 lo = j * nbatch_train
@@ -426,14 +488,9 @@ class Model(object):
                 done = torch.cuda.Event()
                 done.record(main)
                 self._idx_free[e] = done
-                self._uploader.free[self._pp_set][e] = done
+                self._uploader.free[pset][e] = done
         if not spec.recurrent:
-            pp.wait_all()
-            if not self._own_stream:
-                self._shuffler.release_numpy()
-            elif more_updates:
-                self._begin_index_job(pp, noptepochs)
-                self._pp_ahead = True
+            self._close_index_job(job)
         # mean of the loss rows (baselines/ppo2/ppo2.py:139); over the ranks too: 1/size folded in before the SUM
         out = hip.row_mean(self._losses, total, 5, 1.0 / (total * (comm.size if comm is not None else 1)))
         if comm is not None:
@@ -468,10 +525,8 @@ class Model(object):
         nmb = Ng // nbatch_train
         lo, hi = comm.rank * Nl, (comm.rank + 1) * Nl
         main = torch.cuda.current_stream()
-        pp = self._index_pipeline(Ng, noptepochs)
-        if not self._pp_ahead:
-            self._begin_index_job(pp, noptepochs)
-        self._pp_ahead = False
+        self._index_pipeline(Ng, noptepochs)
+        job, pset = self._open_index_job(more_updates)
         total = nmb * noptepochs
         if self._losses.shape[0] < total:
             self._losses = torch.zeros((total, 8), dtype=torch.float32, device=self.device)
@@ -492,7 +547,7 @@ class Model(object):
         advs_ready.record(main)
         row = 0
         for e in range(noptepochs):
-            sig, sig_ready = self._uploader.wait(self._pp_set, e)
+            sig, sig_ready = self._uploader.wait(pset, e)
             d_idx = sig if e == 0 else self._idx_dev[e]
             b = self._share[e]
             with torch.cuda.stream(self._copy_stream):
@@ -509,7 +564,6 @@ class Model(object):
                 ev = torch.cuda.Event()
                 ev.record(self._copy_stream)
             d_prev = d_idx
-            self._set_copied[self._pp_set] = sig_ready
             main.wait_event(ev)
             comm.allreduce_sum_(b["stats"])          # rows become {sum a, sum a^2, B_global}: one collective per epoch
             ev.synchronize()                         # the sizes of this rank's shares (side stream only)
@@ -537,13 +591,8 @@ class Model(object):
             done = torch.cuda.Event()
             done.record(main)
             self._idx_free[e] = done
-            self._uploader.free[self._pp_set][e] = done
-        pp.wait_all()
-        if not self._own_stream:
-            self._shuffler.release_numpy()
-        elif more_updates:
-            self._begin_index_job(pp, noptepochs)
-            self._pp_ahead = True
+            self._uploader.free[pset][e] = done
+        self._close_index_job(job)
         out = hip.row_mean(self._losses, total, 5)
         comm.allreduce_sum_(out)       # per-rank rows are shares of the global means
         comm.poll_checks()
@@ -608,6 +657,7 @@ class Model(object):
         if getattr(self, "_uploader", None) is not None:
             self._uploader_finalizer()
             self._uploader = None
+            self._pps = None
             self._pp_key = None
 
     # ------------------------------------------------------------------ misc surface

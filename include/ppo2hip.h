@@ -181,6 +181,9 @@ int ppo2hip_perm_begin(ppo2hip_perm *p, int nepochs, int32_t *const *out);
 int ppo2hip_perm_begin_relative(ppo2hip_perm *p, int nepochs, int32_t *const *out);
 int ppo2hip_perm_wait(ppo2hip_perm *p, int epoch);   /* blocks until out[epoch] is complete */
 int ppo2hip_perm_wait_all(ppo2hip_perm *p);
+/* Blocks until the running job has drawn all its swap targets: the generator has moved past the job (a second pipeline
+ * on the same generator may begin the next update's job now), although the job's last swaps may still be running. */
+int ppo2hip_perm_wait_drawn(ppo2hip_perm *p);
 /* DEVICE pointers: out[k] = prev[sigma[k]] for k < n (out must not alias prev or sigma). */
 int ppo2hip_compose_i32(const int32_t *prev, const int32_t *sigma, int32_t *out, int64_t n, void *stream);
 
@@ -196,9 +199,9 @@ int ppo2hip_compose_i32(const int32_t *prev, const int32_t *sigma, int32_t *out,
 #define PPO2HIP_FAULT_GRID_SYNC 4u      /* a launch whose workgroups hand values to each other (whole-sequence LSTM, the
                                          * optimiser step folded into ppo2hip_ppo_epoch) gave up waiting for its peers */
 int ppo2hip_take_faults(uint32_t *bits, void *stream);
-/* The same read-and-clear queued on `stream` WITHOUT waiting: the word lands in *host_bits (page-locked HOST memory that
- * stays valid until the copy has run; the caller records an event behind this call and reads the word once the event
- * has completed).  For callers that keep several updates in flight and cannot stall the stream per update; calls on
+/* The same read-and-clear queued on `stream` WITHOUT waiting: a one-thread kernel stores the word into *host_bits
+ * (page-locked HOST memory the device can address, e.g. from hipHostMalloc, that stays valid until the kernel has run;
+ * the caller records an event behind this call and reads the word once the event has completed).  For callers that keep several updates in flight and cannot stall the stream per update; calls on
  * one stream at a time. */
 int ppo2hip_post_faults(uint32_t *host_bits, void *stream);
 
