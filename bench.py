@@ -68,7 +68,7 @@ def measured_traffic(workload, kernels):
         parts = [measured_traffic(workload, k) for k in kernels]
         return None if any(x is None for x in parts) else sum(parts)
     kernel = kernels
-    path = os.path.join(ROOT, "profiles", "r02_%s_hbm_traffic.json" % workload)
+    path = os.path.join(ROOT, "profiles", "r03_%s_hbm_traffic.json" % workload)
     try:
         with open(path) as fh:
             prof = json.load(fh)
@@ -299,21 +299,30 @@ def gradient_roofline(name, cfg, B, grad_ms):
     fused256 = (not image) and cfg["hidden"] == (256, 128)
     achieved_tf = flops_mb / (grad_ms * 1e-3) / 1e12
     peak_tf = MFMA_F32_PEAK_TFLOPS
+    if fused:
+        # layer 2's forward and input-gradient products of both trunks (2 x 2 x 2 H H flops per sample) run on the bf16 pipe
+        # as six piece products per multiply-add, the rest on the float32 pipe: the peak is the algorithmic flops over the
+        # time both pipes need at their dense rates
+        h = cfg["hidden"][0]
+        f_bf16 = 2 * 2 * (2 * h * h) * B
+        peak_tf = flops_mb / ((flops_mb - f_bf16) / MFMA_F32_PEAK_TFLOPS + 6 * f_bf16 / MFMA_BF16_PEAK_TFLOPS)
     if image and cfg["hwc"][2] * 8 == 32:
         # conv1 on the bf16 pipe at three products per multiply-add, the rest on the float32 pipe: the peak is the
         # algorithmic flops over the time both pipes need at their dense rates
         f_bf16 = cnn_conv1_flops_per_sample(cfg["hwc"]) * B
         peak_tf = flops_mb / ((flops_mb - f_bf16) / MFMA_F32_PEAK_TFLOPS + 3 * f_bf16 / MFMA_BF16_PEAK_TFLOPS)
     return {"bound": "mfma",
-            "kernel": ("ppo_grad = mlp_fused16_kernel + fused_finalize_kernel (minibatch gather, forward, loss, "
-                       "backward and weight gradients on fp32 MFMA)") if fused else
+            "kernel": ("ppo_grad = mlp_fused16_kernel + fused_finalize_kernel (minibatch gather, forward, loss, backward and weight "
+                       "gradients; fp32 MFMA except layer 2's forward and input-gradient products, which run on the bf16 pipe as six "
+                       "exact piece products per multiply-add; peak = algorithmic flops over the time the two matrix pipes need at "
+                       "their dense rates)") if fused else
                       ("ppo_grad = gather + mlp_fused256_kernel (forward, loss, input gradients) + mlp_wgrad256_kernel "
                        "(all weight gradients) + slab reduction, fp32 MFMA") if fused256 else
                       ("ppo_grad = gather + layered GEMM / implicit-GEMM conv launches (fp32 MFMA; conv1 on uint8 frames as "
                        "three exact bf16 products per multiply-add) + loss + slab reductions; peak = algorithmic flops over "
                        "the time the two matrix pipes need at their dense rates"),
             "achieved": achieved_tf, "peak": peak_tf, "unit": "TFLOP/s",
-            "frac": achieved_tf / peak_tf,
+            "frac": achieved_tf / peak_tf, "frac_of_fp32_mfma_peak": achieved_tf / MFMA_F32_PEAK_TFLOPS,
             "traffic": measured_traffic(name, "ppo2hip::mlp_fused16_kernel<5, false, 2>") if fused else
                        measured_traffic(name, ("ppo2hip::mlp_fused256_kernel", "ppo2hip::mlp_wgrad256_kernel")) if fused256 else None,
             "flops_per_launch": flops_mb, "ms_per_launch": grad_ms}
@@ -495,6 +504,7 @@ def main():
         return {"bound": "hbm", "kernel": "gae_vec2_kernel<true>", "workload": "65536 envs x 128 steps, R=1 (configs[3], whole, on one GPU)",
                 "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": nbytes, "ms_per_launch": ms,
+                "traffic": measured_traffic("mujoco_mlp64", "ppo2hip::gae_vec2_kernel<true>"),
                 "buffer_sets": nsets, "note": "outputs: returns and returns - values (what the update reads); %d buffer sets of "
                                               "143 MB rotate so the 256 MB Infinity Cache holds none of a launch's operands" % nsets}
     gae_large_roofline = gae_large() if rank == 0 else None
@@ -555,7 +565,7 @@ def main():
                 extra[name] = {"samples_per_s": world * xN * xsteps / xdt, "ms_per_step": xdt / xsteps * 1e3, "steps": xsteps,
                                "warmup": xwarm, "samples_per_step_per_gpu": xN, "nbatch_train": xB,
                                "finite_losses": bool(np.all(np.isfinite(xlosses))),
-                               "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "ms_per_launch")}}
+                               "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_of_fp32_mfma_peak", "ms_per_launch")}}
                 xmodel.close()
                 del xmodel, xro, xstep, xlast, xev
             except Exception as ex:          # a failing extra must not take the headline line with it

@@ -47,7 +47,7 @@ def traffic(workload, db_fetch, db_write, out):
             e["WRITE_SIZE"], e["launches_WRITE_SIZE"] = int(round(write[k][0])), write[k][1]
     doc = {
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a second run, WRITE_SIZE) -- python3 bench.py "
-                   "--steps 5 --warmup 2 --no-cpu-baseline",
+                   "--workload W --steps 5 --warmup 2 --no-cpu-baseline --no-extra-workloads",
         "unit": "bytes per launch (counter KB x 1024, as reported; FETCH_SIZE is uncalibrated for the 4-byte-per-lane "
                 "gathers of the dominant kernel and would need doubling for wide streaming reads)",
         "workload": workload,
