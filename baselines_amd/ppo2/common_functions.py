@@ -36,13 +36,16 @@ class _IndexUploader:
     """Index lists of successive updates, from the permutation pipelines' page-locked buffers to HBM, off the thread
     that feeds the GPU.
 
-    Two pipelines on ONE generator take the updates' jobs in turn (job k: pipeline and buffer set k % 2).  A scheduler
-    thread begins job k as soon as (i) the caller has asked for it (``request``), (ii) job k - 1 has drawn all its swap
-    targets — the generator is free, although that job's last swaps still run, so consecutive jobs overlap and the
-    period is the serial draw time, not the job time — and (iii) the caller has finished queueing update k - 2, whose
-    buffers job k reuses.  An uploader thread with a stream of its own copies each list into a staging buffer as the
-    pipeline finishes it.  hipMemcpyAsync from page-locked memory now and then holds its calling thread for 3-6 ms (the
-    runtime call itself: torch's copy_ and a bare call alike); here that only delays a copy nobody is waiting for yet.
+    Several pipelines on ONE generator take the updates' jobs in turn (job k: pipeline and buffer set k mod their
+    number).  A scheduler thread begins job k as soon as (i) the caller has asked for it (``request``), (ii) job k - 1
+    has drawn all its swap targets — the generator is free, although that job's last swaps still run, so consecutive
+    jobs overlap and the period is the serial draw time, not the job time — and (iii) the caller has finished queueing
+    the update whose buffers job k reuses.  An uploader thread with a stream of its own copies each list into a staging
+    buffer as the pipeline finishes it.  hipMemcpyAsync from page-locked memory now and then holds its calling thread
+    for 3-6 ms (the runtime call itself: torch's copy_ and a bare call alike); with the lists generated up to two updates
+    ahead that delays a copy nobody is waiting for yet.  (A copy kernel instead of the copy engine avoids the stall but
+    costs more than it saves: the gradient kernel's workgroups take every vector register of a CU, so they cannot start
+    on a CU while any other kernel's wave is resident there — measured +0.14 ms per update.)
     ``stage[s][e]`` receives epoch e of the job in set s; ``ready`` is the event after its copy, ``free`` the event (set
     by the consumer) after which the staging buffer may be overwritten."""
 
@@ -108,7 +111,8 @@ class _IndexUploader:
         try:
             while True:
                 with self.cv:
-                    self.cv.wait_for(lambda: self.quit or (self.jobs_begun < self.jobs_wanted and self.jobs_used >= self.jobs_begun - 1))
+                    self.cv.wait_for(lambda: self.quit or (self.jobs_begun < self.jobs_wanted and
+                                                           self.jobs_used >= self.jobs_begun - (len(self.pps) - 1)))
                     if self.quit:
                         return
                     k = self.jobs_begun
@@ -305,6 +309,8 @@ class Model(object):
         self._shuffler = hip.LegacyShuffler(seed)
         self._own_stream = True
 
+    INDEX_SETS = 3      # permutation pipelines / buffer sets: index lists are generated up to INDEX_SETS - 1 updates ahead
+
     def _index_pipeline(self, N, noptepochs):
         key = (N, noptepochs)
         if getattr(self, "_pp_key", None) != key:
@@ -313,8 +319,9 @@ class Model(object):
                 self._own_stream = False
             if getattr(self, "_uploader", None) is not None:
                 self._uploader_finalizer()
-            # two pipelines on the one generator: consecutive updates' jobs overlap (see _IndexUploader)
-            self._pps = [hip.PermPipeline(self._shuffler, N, noptepochs, nsets=1) for _ in range(2)]
+            # three pipelines on the one generator: consecutive updates' jobs overlap and run up to two updates ahead
+            # (see _IndexUploader)
+            self._pps = [hip.PermPipeline(self._shuffler, N, noptepochs, nsets=1) for _ in range(self.INDEX_SETS)]
             self._pp_key = key
             self._job = 0                  # number of the job (= update with this shape) the next call consumes
             self._idx_dev = [torch.empty(N, dtype=torch.int32, device=self.device) for _ in range(noptepochs)]
@@ -336,12 +343,12 @@ class Model(object):
             self._shuffler.adopt_numpy()
             up.request(k + 1)
         else:
-            up.request(k + 2 if more_updates else k + 1)
-        return k, k % 2
+            up.request(k + self.INDEX_SETS if more_updates else k + 1)
+        return k, k % self.INDEX_SETS
 
     def _close_index_job(self, k):
         if not self._own_stream:
-            self._pps[k % 2].wait_all()
+            self._pps[k % self.INDEX_SETS].wait_all()
             self._shuffler.release_numpy()
         self._uploader.consumed(k)
         self._job = k + 1
