@@ -32,6 +32,20 @@ class DeviceRollout:
         self.advs = None   # scalar advantage fed to the update: float32 or float64 [T, E]
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device):
+    """(upload stream, side compute stream) of a device, created once per process and shared by every model: the runtime
+    maps streams onto a handful of hardware queues in creation order, and side streams created anew per model end up
+    sharing a queue with the stream that carries the gradient kernels — their copies and small kernels then queue up
+    behind the very launches they are meant to run beside."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _SIDE_STREAMS[key]
+
+
 class _IndexUploader:
     """Index lists of successive updates, from the permutation pipelines' page-locked buffers to HBM, off the thread
     that feeds the GPU.
@@ -53,7 +67,7 @@ class _IndexUploader:
         import queue
         import threading
         self.device, self.pps, self.nepochs = device, pps, nepochs
-        self.stream = torch.cuda.Stream(device=device)
+        self.stream = _side_streams(device)[0]
         nsets = len(pps)
         self.stage = [[torch.empty(n, dtype=torch.int32, device=device) for _ in range(nepochs)] for _ in range(nsets)]
         self.ready = [[None] * nepochs for _ in range(nsets)]
@@ -330,7 +344,7 @@ class Model(object):
             import weakref
             self._uploader_finalizer = weakref.finalize(self, self._uploader.close)
             self._idx_free = [None] * noptepochs      # main-stream event: kernels reading _idx_dev[e] done
-            self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._copy_stream = _side_streams(self.device)[1]
             self._side_stats = [None] * noptepochs    # per epoch: (workspace, out) of the advantage statistics taken on the side stream
         return self._uploader
 

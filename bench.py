@@ -544,7 +544,9 @@ def main():
                 continue
             xcfg = WORKLOADS[name]
             xN, xB = xcfg["T"] * xcfg["E"], xcfg["T"] * xcfg["E"] // xcfg["nmb"]
-            xsteps, xwarm = (20, 5) if "hwc" not in xcfg else (3, 2)
+            # (a model built later in a process runs its first twenty-odd updates about 1 ms slower — new worker threads
+            # and buffers settling — so the millisecond-scale MLP updates get a warm-up that covers it)
+            xsteps, xwarm = (20, 30) if "hwc" not in xcfg else (3, 2)
             try:
                 xmodel, xro, xstep = build_workload(xcfg, device, comm, rank)
                 for _ in range(xwarm):
