@@ -532,14 +532,34 @@ def main():
     del src, ga, gb
 
     # the other workloads, a few steps each behind the headline region: the same step function, timed the same way
-    # (barrier + synchronize on both sides, max over ranks), so that their figures come out of this run too
-    cpu_line = cpu_baseline(model, ro, cfg) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
+    # (barrier + synchronize on both sides, max over ranks), so that their figures come out of this run too.  With
+    # several ranks only the two configurations that name several GPUs run (the env-sharded MLP and cnn + LSTM), and a
+    # watchdog guards them: should an extra hang (a rank lost inside a collective), every rank gives up after
+    # EXTRA_TIMEOUT_S, rank 0 prints the headline line it already has, and the processes exit.
     extra = {}
+    cpu_line = cpu_baseline(model, ro, cfg) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
+    headline = None
+    if rank == 0:
+        headline = headline_line(args, cfg, world, N, B, T, E, A, R, D, image, dt, step_ms, priming, grad_ms, gae_ms,
+                                 gae_large_roofline, copy_gbs, sgemm_tf, losses, comm_info, cpu_line)
     if not args.no_extra_workloads:
+        import threading
+        fired = threading.Event()
+
+        def give_up():
+            fired.set()
+            if rank == 0:
+                headline["workloads"] = dict(extra, error="an extra workload did not finish within %d s; abandoned" % EXTRA_TIMEOUT_S)
+                print(json.dumps(headline), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(EXTRA_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         model.close()
         del model, ro, step, outs
         torch.cuda.empty_cache()
-        for name in ("mlp_env_shard", "mujoco_fork", "atari_cnn", "atari_lstm", "mujoco_mlp64"):
+        names = ("mlp_env_shard", "mujoco_fork", "atari_cnn", "atari_lstm", "mujoco_mlp64") if world == 1 else ("mlp_env_shard", "atari_lstm")
+        for name in names:
             if name == args.workload:
                 continue
             xcfg = WORKLOADS[name]
@@ -572,49 +592,63 @@ def main():
                 del xmodel, xro, xstep, xlast, xev
             except Exception as ex:          # a failing extra must not take the headline line with it
                 extra[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                if world > 1:
+                    break                    # the ranks may no longer be in step: no further collectives
             torch.cuda.empty_cache()
+        watchdog.cancel()
+        if fired.is_set():
+            time.sleep(3600)                 # the watchdog is printing and exiting
 
     if rank == 0:
-        if image:
-            shape = "Atari-shaped rollout: %dx%dx%d uint8 obs, nature_cnn%s Categorical(%d)" % (
-                cfg["hwc"] + (" + LSTM(%d), env-sequence minibatches," % cfg["nlstm"] if cfg.get("nlstm") else "", A))
-            which = "configs[4]" if cfg.get("nlstm") else "configs[2]"
-        else:
-            shape = "MuJoCo-shaped rollout: obs_dim=%d act_dim=%d Gaussian MLP%s" % (D, A, str(cfg["hidden"]).replace(" ", ""))
-            which = "configs[3] shard" if args.workload == "mlp_env_shard" else "configs[1]"
-        gae_bytes = T * E * (16 * R + 1) + E * (4 * R + 1)
-        gae_gbs = gae_bytes / (gae_ms * 1e-3) / 1e9
-        out = {
-            "metric": "PPO2 samples/sec (GAE+update)", "value": world * N * args.steps / dt, "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "priming_steps": priming, "ms_per_step": dt / args.steps * 1e3,
-            "ms_per_step_gpu_events": {"median": step_ms[len(step_ms) // 2], "min": step_ms[0], "max": step_ms[-1]},
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s synthetic %s nenvs=%d nsteps=%d per GPU, %d minibatches x %d epochs, %s loss"
-                                   % (which, shape, E, T, cfg["nmb"], cfg["noptepochs"], "upstream" if cfg["upstream"] else "fork"),
-                       "samples_per_step_per_gpu": N, "nbatch_train": B,
-                       "parallelism": "env-sharded dp%d, RCCL grad all-reduce (MpiAdam semantics)" % world if world > 1 else "single GPU"},
-            "roofline": gradient_roofline(args.workload, cfg, B, grad_ms),
-            "gae_roofline": {"bound": "hbm", "kernel": "gae_tiled_kernel", "achieved": gae_gbs, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": gae_gbs / HBM_PEAK_GBS, "bytes_per_launch": gae_bytes,
-                             "traffic": measured_traffic(args.workload, "ppo2hip::gae_tiled_kernel"),
-                             "ms_per_launch": gae_ms},
-            "gae_roofline_large": gae_large_roofline,
-            "device_measured": {"copy_gbs": copy_gbs, "gae_large_vs_copy": (gae_large_roofline["achieved"] / copy_gbs) if gae_large_roofline else None,
-                                "library_sgemm_tflops": sgemm_tf,
-                                "note": "1 GiB device-to-device copy (read + write) and an 8192^3 fp32 torch.matmul on this card"},
-            "losses": [float(x) for x in losses],
-        }
-        if comm_info is not None:
-            out["comm"] = comm_info
         if extra:
-            out["workloads"] = extra
-        if cpu_line is not None:
-            out["cpu_baseline"] = cpu_line
-        print(json.dumps(out))
+            headline["workloads"] = extra
+        print(json.dumps(headline))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+EXTRA_TIMEOUT_S = 240
+
+
+def headline_line(args, cfg, world, N, B, T, E, A, R, D, image, dt, step_ms, priming, grad_ms, gae_ms, gae_large_roofline,
+                  copy_gbs, sgemm_tf, losses, comm_info, cpu_line):
+    """The JSON object of the headline workload (rank 0)."""
+    if image:
+        shape = "Atari-shaped rollout: %dx%dx%d uint8 obs, nature_cnn%s Categorical(%d)" % (
+            cfg["hwc"] + (" + LSTM(%d), env-sequence minibatches," % cfg["nlstm"] if cfg.get("nlstm") else "", A))
+        which = "configs[4]" if cfg.get("nlstm") else "configs[2]"
+    else:
+        shape = "MuJoCo-shaped rollout: obs_dim=%d act_dim=%d Gaussian MLP%s" % (D, A, str(cfg["hidden"]).replace(" ", ""))
+        which = "configs[3] shard" if args.workload == "mlp_env_shard" else "configs[1]"
+    gae_bytes = T * E * (16 * R + 1) + E * (4 * R + 1)
+    gae_gbs = gae_bytes / (gae_ms * 1e-3) / 1e9
+    out = {
+        "metric": "PPO2 samples/sec (GAE+update)", "value": world * N * args.steps / dt, "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "priming_steps": priming, "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step_gpu_events": {"median": step_ms[len(step_ms) // 2], "min": step_ms[0], "max": step_ms[-1]},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s synthetic %s nenvs=%d nsteps=%d per GPU, %d minibatches x %d epochs, %s loss"
+                               % (which, shape, E, T, cfg["nmb"], cfg["noptepochs"], "upstream" if cfg["upstream"] else "fork"),
+                   "samples_per_step_per_gpu": N, "nbatch_train": B,
+                   "parallelism": "env-sharded dp%d, RCCL grad all-reduce (MpiAdam semantics)" % world if world > 1 else "single GPU"},
+        "roofline": gradient_roofline(args.workload, cfg, B, grad_ms),
+        "gae_roofline": {"bound": "hbm", "kernel": "gae_tiled_kernel", "achieved": gae_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gae_gbs / HBM_PEAK_GBS, "bytes_per_launch": gae_bytes,
+                         "traffic": measured_traffic(args.workload, "ppo2hip::gae_tiled_kernel"),
+                         "ms_per_launch": gae_ms},
+        "gae_roofline_large": gae_large_roofline,
+        "device_measured": {"copy_gbs": copy_gbs, "gae_large_vs_copy": (gae_large_roofline["achieved"] / copy_gbs) if gae_large_roofline else None,
+                            "library_sgemm_tflops": sgemm_tf,
+                            "note": "1 GiB device-to-device copy (read + write) and an 8192^3 fp32 torch.matmul on this card"},
+        "losses": [float(x) for x in losses],
+    }
+    if comm_info is not None:
+        out["comm"] = comm_info
+    if cpu_line is not None:
+        out["cpu_baseline"] = cpu_line
+    return out
 
 
 if __name__ == "__main__":
