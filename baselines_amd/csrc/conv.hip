@@ -374,7 +374,7 @@ int conv_forward(const void *X, bool x_u8, const float *W, const float *b, float
     RowMajor Bm{W, c.Cout};
     EpiBiasAct ep{Y, c.Cout, b, ACT_RELU, 0, x_u8 ? kU8Scale : 1.f};
     if (x_u8) return launch_gemm(Im2col<true>{X, geom(c)}, Bm, ep, M, c.Cout, K, 1, s, "conv_forward");
-    return launch_gemm(Im2col<false>{X, geom(c)}, Bm, ep, M, c.Cout, K, 1, s, "conv_forward");
+    return launch_gemm<true>(Im2col<false>{X, geom(c)}, Bm, ep, M, c.Cout, K, 1, s, "conv_forward");
 }
 
 int conv_wgrad_max_slabs(const ConvShape &c) {
@@ -397,7 +397,7 @@ int conv_wgrad_slabs(const void *X, bool x_u8, const float *dY, const ConvShape 
     const int64_t ones = sep ? -1 : K, rows = sep ? K : K + 1;
     int rc;
     if (x_u8) rc = launch_gemm(Im2colT<true>{Im2col<true>{X, geom(c)}, ones}, Bm, ep, rows, c.Cout, M, n, s, "conv_wgrad");
-    else rc = launch_gemm(Im2colT<false>{Im2col<false>{X, geom(c)}, ones}, Bm, ep, rows, c.Cout, M, n, s, "conv_wgrad");
+    else rc = launch_gemm<true>(Im2colT<false>{Im2col<false>{X, geom(c)}, ones}, Bm, ep, rows, c.Cout, M, n, s, "conv_wgrad");
     if (rc || !sep || !bias_rows) return rc;
     return slab_bias_rows(dY, c.Cout, M, K, c.Cout, slabs, n, s);
 }
@@ -502,7 +502,7 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
             const PixelMajor q{geom(c), 0, 0, IHp, IWp, KHp, KWp, 1, 0, 0, 0};
             const int64_t Mq = (int64_t)c.B * IHp * IWp;
             if (nrows && colsum_rows) *nrows = (int)(gemm_row_tiles(Mq, S * S * c.Cin, 1) * S * S);      // [tile][class][ci]
-            return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, colsum_rows, relu_bits}, Mq, S * S * c.Cin,
+            return launch_gemm<true>(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, colsum_rows, relu_bits}, Mq, S * S * c.Cin,
                                KHp * KWp * c.Cout, 1, s, "conv_dgrad");
         }
         for (int ph = 0; ph < S; ph++)
@@ -528,7 +528,7 @@ int conv_dgrad(const float *dY, const float *W, const float *Xact, float *dX, co
     if (c.stride == 1 && pixel_major_ok(c, M) && c.KH <= c.IH && c.KW <= c.IW) {
         const PixelMajor q{geom(c), 0, 0, c.IH, c.IW, c.KH, c.KW, 0, 0, 0, 0};
         if (nrows && colsum_rows) *nrows = (int)gemm_row_tiles(M, c.Cin, 1);
-        return launch_gemm(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, colsum_rows, relu_bits}, M, c.Cin, K, 1, s, "conv_dgrad");
+        return launch_gemm<true>(DgradColPM{dY, q}, DgradWPM{W, q}, EpiActGradPM{dX, Xact, q, colsum_rows, relu_bits}, M, c.Cin, K, 1, s, "conv_dgrad");
     }
     EpiActGrad ep{dX, c.Cin, Xact, c.Cin, ACT_RELU, 0, nullptr};
     return launch_gemm(DgradCol{dY, geom(c)}, DgradW{W, geom(c)}, ep, M, c.Cin, K, 1, s, "conv_dgrad");

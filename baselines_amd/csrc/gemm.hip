@@ -12,7 +12,7 @@ int fc_forward(const float *X, int ldx, const float *W, const float *b, float *Y
     RowMajor A{X, ldx};
     RowMajor B{W, N};
     EpiBiasAct ep{Y, ldy, b, act, accumulate ? 1 : 0};
-    return launch_gemm(A, B, ep, M, N, K, 1, s, "fc_forward");
+    return launch_gemm<true>(A, B, ep, M, N, K, 1, s, "fc_forward");
 }
 
 int fc_dgrad(const float *dY, int lddy, const float *W, int Kin, int N, const float *H, int ldh, int act,
@@ -21,7 +21,7 @@ int fc_dgrad(const float *dY, int lddy, const float *W, int Kin, int N, const fl
     Transposed B{W, N};   // B(k = n, j = kin) = W[kin][n]
     EpiActGrad ep{dX, lddx, H, ldh, act, accumulate ? 1 : 0, colsum_tiles};
     if (ntiles) *ntiles = (int)gemm_row_tiles(M, Kin, 1);
-    return launch_gemm(A, B, ep, M, Kin, N, 1, s, "fc_dgrad");
+    return launch_gemm<true>(A, B, ep, M, Kin, N, 1, s, "fc_dgrad");
 }
 
 int fc_forward_parts(const float *X, int ldx, const float *W, int M, int N, int K, int nparts, float *parts, hipStream_t s) {
@@ -116,7 +116,7 @@ int fc_wgrad_slabs(const float *X, int ldx, const float *dY, int lddy, int64_t S
     EpiSlab ep{slabs, N, (int64_t)(Kin + 1) * N};
     if (wgrad_bias_separately(Kin)) {
         TransposedOnes A{X, ldx, -1};    // no ones-row: rows 0 .. Kin-1 only
-        int rc = launch_gemm(A, B, ep, Kin, N, S, n, s, "fc_wgrad");
+        int rc = launch_gemm<true>(A, B, ep, Kin, N, S, n, s, "fc_wgrad");
         if (rc || !bias_rows) return rc;
         return slab_bias_rows(dY, lddy, S, Kin, N, slabs, n, s);
     }

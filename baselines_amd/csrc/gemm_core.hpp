@@ -21,7 +21,34 @@
 namespace ppo2hip {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short gemm_bf16x8 __attribute__((ext_vector_type(8)));
 
+// A float32 is the exact sum of three bf16 numbers (its 24 significand bits in runs of eight, each piece what truncating
+// the remainder to bf16 leaves).  PIECES products cut both operands into such pieces and run on the bf16 matrix pipe:
+// of the nine piece products the six whose weight is 2^-16 of the result or more are kept — every kept product is exact
+// in the float32 accumulator, what is dropped is below 2^-24 of its term, the rounding class of the float32 fma chain —
+// and v_mfma_f32_32x32x16_bf16 retires a 16-deep slab of a 32 x 32 block in 6 instructions of 32 cycles where
+// v_mfma_f32_32x32x2_f32 takes 8 of 64 on the vector ALUs.
+// The tiles stay float32 in LDS, k-major as for the float32 products, and each lane cuts the eight k of its operand
+// row as it reads them.  Cutting on the way INTO LDS instead (piece tiles, 16-byte operand reads) measured the same
+// for the k-contiguous operands and cannot serve the m / n-contiguous ones of the weight gradients at all; two LDS
+// buffers with two slabs of loads in flight lost a resident workgroup per CU and with it more than the barrier saved.
+__device__ __forceinline__ void cut3(float x, unsigned &h, unsigned &m, unsigned &l) {      // pieces in the UPPER halves
+    h = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(h);          // exact: the low sixteen significand bits
+    m = __float_as_uint(r1) & 0xffff0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));     // exact: at most eight bits, a bf16 as it stands
+}
+// eight k-consecutive elements -> their three pieces as MFMA operands
+__device__ __forceinline__ void cut_run8(const float *v, uint4 *out) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) cut3(v[j], h[j], m[j], l[j]);
+    auto pk = [](unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); };
+    out[0] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), pk(h[6], h[7]));
+    out[1] = make_uint4(pk(m[0], m[1]), pk(m[2], m[3]), pk(m[4], m[5]), pk(m[6], m[7]));
+    out[2] = make_uint4(pk(l[0], l[1]), pk(l[2], l[3]), pk(l[4], l[5]), pk(l[6], l[7]));
+}
 constexpr int GEMM_BN = 64;        // widest tile
 constexpr int GEMM_BK = 16;
 constexpr int GEMM_THREADS = 256;
@@ -79,7 +106,8 @@ __host__ __device__ constexpr int lds_pitch(int width, int mode) {
 // FULLK: every slab of every tile is a whole 16 steps of k (K, the split length and a tile-dependent k range are all
 // multiples of 16), so the loads need neither tests nor zero-fill — with float32 matrix products every vector instruction
 // saved in the main loop is matrix time won.
-template <class AL, class BL, class EP, int WM, int NB, int AV, int BV, bool FULLK = false>
+// PIECES: the products run as bf16 piece products on the bf16 pipe (see cut3)
+template <class AL, class BL, class EP, int WM, int NB, int AV, int BV, bool FULLK = false, bool PIECES = false>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, int64_t M, int N, int64_t K,
                                                             int64_t klen) {
     constexpr int BM = 32 * WM;
@@ -361,6 +389,27 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
             stash();
             __syncthreads();
             if (k0 + GEMM_BK < kend) fetch(k0 + GEMM_BK);
+            if constexpr (PIECES) {
+                // lane (li, lh) owns k = 8 lh .. 8 lh + 7 of its operand row: eight reads across the LDS rows
+                float ar[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) ar[j] = As[(8 * lh + j) * LDA + wm * 32 + li];
+                uint4 af[3];
+                cut_run8(ar, af);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    float br[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) br[j] = Bs[(8 * lh + j) * LDB + (wn * NB + nb) * 32 + li];
+                    uint4 bf[3];
+                    cut_run8(br, bf);
+                    constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int t = 0; t < 6; t++)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gemm_bf16x8, af[pa[t]]),
+                                                                          __builtin_bit_cast(gemm_bf16x8, bf[pb[t]]), acc[nb], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int kk = 0; kk < GEMM_BK / 2; kk++) {
                 const float av = As[(2 * kk + lh) * LDA + wm * 32 + li];
@@ -433,7 +482,9 @@ struct has_full_slabs : std::false_type {};
 template <class L>
 struct has_full_slabs<L, std::void_t<decltype(std::declval<const L &>().full_slabs())>> : std::true_type {};
 
-template <class AL, class BL, class EP, int AV, int BV>
+// PIECES: a call site's opt-in to the bf16-piece form for its wide, whole-slab shape (one more instantiation per
+// product, so only the products that carry a workload ask for it); PPO2HIP_GEMM_FP32 in the environment turns it off
+template <bool PIECES, class AL, class BL, class EP, int AV, int BV>
 inline int launch_gemm_v(const AL &a, const BL &b, const EP &ep, int64_t M, int N, int64_t K, int64_t klen, dim3 grid,
                          bool small_m, bool narrow, hipStream_t s, const char *what) {
     static const bool no_fullk = getenv("PPO2HIP_GEMM_CHECKED") != nullptr;
@@ -449,9 +500,16 @@ inline int launch_gemm_v(const AL &a, const BL &b, const EP &ep, int64_t M, int 
         hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 1, AV, BV, true>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
     else if (narrow)
         hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 1, AV, BV>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
-    else if (fullk)
+    else if (fullk) {
+        if constexpr (PIECES && AV == AL::kVec && BV == BL::kVec) {
+            static const bool no_pieces = getenv("PPO2HIP_GEMM_FP32") != nullptr;
+            if (!no_pieces) {
+                hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 2, AV, BV, true, true>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
+                return check_launch(what);
+            }
+        }
         hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 2, AV, BV, true>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
-    else
+    } else
         hipLaunchKernelGGL((gemm_kernel<AL, BL, EP, 4, 2, AV, BV>), grid, dim3(GEMM_THREADS), 0, s, a, b, ep, M, N, K, klen);
     return check_launch(what);
 }
@@ -463,7 +521,7 @@ inline bool gemm_small_m(int64_t M, int N, int nsplit) {
 }
 inline int64_t gemm_row_tiles(int64_t M, int N, int nsplit) { return ceil_div(M, gemm_small_m(M, N, nsplit < 1 ? 1 : nsplit) ? 64 : 128); }
 
-template <class AL, class BL, class EP>
+template <bool PIECES = false, class AL, class BL, class EP>
 inline int launch_gemm(const AL &a, const BL &b, const EP &ep, int64_t M, int N, int64_t K, int nsplit,
                        hipStream_t s, const char *what) {
     if (M <= 0 || N <= 0) return 0;
@@ -486,15 +544,15 @@ inline int launch_gemm(const AL &a, const BL &b, const EP &ep, int64_t M, int N,
     bool bv = false;
     if constexpr (BVmax > 1) bv = b.vec_width() == BVmax && (BL::kInnerFast ? N % BVmax == 0 : K % BVmax == 0);
     if constexpr (AVmax > 1 && BVmax > 1) {
-        if (av && bv) return launch_gemm_v<AL, BL, EP, AVmax, BVmax>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
+        if (av && bv) return launch_gemm_v<PIECES, AL, BL, EP, AVmax, BVmax>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
     }
     if constexpr (AVmax > 1) {
-        if (av) return launch_gemm_v<AL, BL, EP, AVmax, 1>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
+        if (av) return launch_gemm_v<PIECES, AL, BL, EP, AVmax, 1>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
     }
     if constexpr (BVmax > 1) {
-        if (bv) return launch_gemm_v<AL, BL, EP, 1, BVmax>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
+        if (bv) return launch_gemm_v<PIECES, AL, BL, EP, 1, BVmax>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
     }
-    return launch_gemm_v<AL, BL, EP, 1, 1>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
+    return launch_gemm_v<PIECES, AL, BL, EP, 1, 1>(a, b, ep, M, N, K, klen, grid, small_m, narrow, s, what);
 }
 
 // ---- loaders ---------------------------------------------------------------------------
