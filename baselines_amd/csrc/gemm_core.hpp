@@ -23,27 +23,34 @@ namespace ppo2hip {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short gemm_bf16x8 __attribute__((ext_vector_type(8)));
 
-// A float32 is the exact sum of three bf16 numbers (its 24 significand bits in runs of eight, each piece what truncating
-// the remainder to bf16 leaves).  PIECES products cut both operands into such pieces and run on the bf16 matrix pipe:
-// of the nine piece products the six whose weight is 2^-16 of the result or more are kept — every kept product is exact
-// in the float32 accumulator, what is dropped is below 2^-24 of its term, the rounding class of the float32 fma chain —
-// and v_mfma_f32_32x32x16_bf16 retires a 16-deep slab of a 32 x 32 block in 6 instructions of 32 cycles where
-// v_mfma_f32_32x32x2_f32 takes 8 of 64 on the vector ALUs.
+// A float32 is the exact sum of three bf16 numbers: h = x rounded to bf16 (half an ulp added, then truncated),
+// m = x - h truncated to bf16 (x - h is exact and has at most 16 significant bits), l = x - h - m (at most 8 bits: a
+// bf16 as it stands).  PIECES products cut both operands into such pieces and run on the bf16 matrix pipe: of the nine
+// piece products the six whose weight is 2^-17 of the result or more are kept — every kept product is exact, what is
+// dropped (m l, l m, l l) is below 2^-24 of its term — and v_mfma_f32_32x32x16_bf16 retires a 16-deep slab of a
+// 32 x 32 block in 6 instructions of 32 cycles where v_mfma_f32_32x32x2_f32 takes 8 of 64 on the vector ALUs.
+// Rounding h (not truncating it) is what keeps sums of same-signed terms unbiased: m and l then take either sign, and
+// the matrix pipe's truncation of small addends against a large accumulator cancels instead of adding up.  Measured
+// against float64 on K = 3136 with all-positive operands, mean error over sum |a b|: 4.3e-7 (float32 pipe 6.7e-7,
+// all three pieces truncated 8.0e-6); with operands of either sign all forms give 1.7e-8 (float32 pipe 2.0e-8).
 // The tiles stay float32 in LDS, k-major as for the float32 products, and each lane cuts the eight k of its operand
 // row as it reads them.  Cutting on the way INTO LDS instead (piece tiles, 16-byte operand reads) measured the same
 // for the k-contiguous operands and cannot serve the m / n-contiguous ones of the weight gradients at all; two LDS
-// buffers with two slabs of loads in flight lost a resident workgroup per CU and with it more than the barrier saved.
-__device__ __forceinline__ void cut3(float x, unsigned &h, unsigned &m, unsigned &l) {      // pieces in the UPPER halves
-    h = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(h);          // exact: the low sixteen significand bits
-    m = __float_as_uint(r1) & 0xffff0000u;
-    l = __float_as_uint(r1 - __uint_as_float(m));     // exact: at most eight bits, a bf16 as it stands
-}
+// buffers with two slabs of loads in flight lost a resident workgroup per CU and with it more than the barrier saved;
+// 128-column tiles (the A tile cut once for twice the columns) lost to the same: 64 accumulator registers more;
+// v_cvt_pk_bf16_f32 for all three pieces (round to nearest even throughout) cost 12 % of the product's time, rounding
+// h alone as here 2.5 % of an Atari update over truncating everything.
 // eight k-consecutive elements -> their three pieces as MFMA operands
 __device__ __forceinline__ void cut_run8(const float *v, uint4 *out) {
     unsigned h[8], m[8], l[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) cut3(v[j], h[j], m[j], l[j]);
+    for (int j = 0; j < 8; j++) {
+        h[j] = (__float_as_uint(v[j]) + 0x8000u) & 0xffff0000u;
+        const float r = v[j] - __uint_as_float(h[j]);
+        m[j] = __float_as_uint(r) & 0xffff0000u;
+        l[j] = __float_as_uint(r - __uint_as_float(m[j]));
+    }
+    // upper halves of two floats side by side: bytes 2, 3 of the first, then of the second
     auto pk = [](unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); };
     out[0] = make_uint4(pk(h[0], h[1]), pk(h[2], h[3]), pk(h[4], h[5]), pk(h[6], h[7]));
     out[1] = make_uint4(pk(m[0], m[1]), pk(m[2], m[3]), pk(m[4], m[5]), pk(m[6], m[7]));
@@ -390,17 +397,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(AL a, BL b, EP ep, i
             __syncthreads();
             if (k0 + GEMM_BK < kend) fetch(k0 + GEMM_BK);
             if constexpr (PIECES) {
-                // lane (li, lh) owns k = 8 lh .. 8 lh + 7 of its operand row: eight reads across the LDS rows
+                // lane (li, lh) takes k = lh, 2 + lh, ..., 14 + lh of its operand row (any split of the slab's sixteen k
+                // over the two lane halves serves, as long as A and B agree): the rows the float32 products read, whose
+                // pitch keeps the two halves on different banks
                 float ar[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) ar[j] = As[(8 * lh + j) * LDA + wm * 32 + li];
+                for (int j = 0; j < 8; j++) ar[j] = As[(2 * j + lh) * LDA + wm * 32 + li];
                 uint4 af[3];
                 cut_run8(ar, af);
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) {
                     float br[8];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) br[j] = Bs[(8 * lh + j) * LDB + (wn * NB + nb) * 32 + li];
+                    for (int j = 0; j < 8; j++) br[j] = Bs[(2 * j + lh) * LDB + (wn * NB + nb) * 32 + li];
                     uint4 bf[3];
                     cut_run8(br, bf);
                     constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};
