@@ -96,6 +96,12 @@ def cnn_flops_per_sample(hwc, nact, nlstm=0):
     return 3 * fwd - conv1
 
 
+def lstm_recurrent_flops_per_sample(nlstm):
+    """The part of cnn_flops_per_sample that stays on the float32 pipe: the h . Wh products inside the whole-sequence
+    kernels, forward and input gradient (their weight gradient is one wide product over all steps and runs as pieces)."""
+    return 2 * (2 * nlstm * 4 * nlstm)
+
+
 def cnn_conv1_flops_per_sample(hwc):
     """The part of cnn_flops_per_sample that runs as bf16 products (three per float32 multiply-add: the uint8 operand is
     exact in bf16, the float32 one is cut into three exact bf16 pieces): conv1 forward and weight gradient."""
@@ -306,11 +312,13 @@ def gradient_roofline(name, cfg, B, grad_ms):
         h = cfg["hidden"][0]
         f_bf16 = 2 * 2 * (2 * h * h) * B
         peak_tf = flops_mb / ((flops_mb - f_bf16) / MFMA_F32_PEAK_TFLOPS + 6 * f_bf16 / MFMA_BF16_PEAK_TFLOPS)
-    if image and cfg["hwc"][2] * 8 == 32:
-        # conv1 on the bf16 pipe at three products per multiply-add, the rest on the float32 pipe: the peak is the
-        # algorithmic flops over the time both pipes need at their dense rates
-        f_bf16 = cnn_conv1_flops_per_sample(cfg["hwc"]) * B
-        peak_tf = flops_mb / ((flops_mb - f_bf16) / MFMA_F32_PEAK_TFLOPS + 3 * f_bf16 / MFMA_BF16_PEAK_TFLOPS)
+    if image:
+        # every wide product runs on the bf16 pipe: conv1 at three piece products per multiply-add (its uint8 operand is
+        # one piece), the others at six; the recurrent h . Wh products of the sequence kernels stay on the float32
+        # pipe.  The peak is the algorithmic flops over the time the two pipes need at their dense rates.
+        f_conv1 = cnn_conv1_flops_per_sample(cfg["hwc"]) * B if cfg["hwc"][2] * 8 == 32 else 0
+        f_rec = lstm_recurrent_flops_per_sample(cfg["nlstm"]) * B if cfg.get("nlstm") else 0
+        peak_tf = flops_mb / (f_rec / MFMA_F32_PEAK_TFLOPS + (3 * f_conv1 + 6 * (flops_mb - f_conv1 - f_rec)) / MFMA_BF16_PEAK_TFLOPS)
     return {"bound": "mfma",
             "kernel": ("ppo_grad = mlp_fused16_kernel + fused_finalize_kernel (minibatch gather, forward, loss, backward and weight "
                        "gradients; fp32 MFMA except layer 2's forward and input-gradient products, which run on the bf16 pipe as six "
@@ -318,9 +326,10 @@ def gradient_roofline(name, cfg, B, grad_ms):
                        "their dense rates)") if fused else
                       ("ppo_grad = gather + mlp_fused256_kernel (forward, loss, input gradients) + mlp_wgrad256_kernel "
                        "(all weight gradients) + slab reduction, fp32 MFMA") if fused256 else
-                      ("ppo_grad = gather + layered GEMM / implicit-GEMM conv launches (fp32 MFMA; conv1 on uint8 frames as "
-                       "three exact bf16 products per multiply-add) + loss + slab reductions; peak = algorithmic flops over "
-                       "the time the two matrix pipes need at their dense rates"),
+                      ("ppo_grad = gather + layered GEMM / implicit-GEMM conv launches (bf16 pipe: six exact piece products per "
+                       "float32 multiply-add, three for conv1 on uint8 frames; float32 pipe for the recurrent products of the "
+                       "sequence kernels) + loss + slab reductions; peak = algorithmic flops over the time the two matrix "
+                       "pipes need at their dense rates"),
             "achieved": achieved_tf, "peak": peak_tf, "unit": "TFLOP/s",
             "frac": achieved_tf / peak_tf, "frac_of_fp32_mfma_peak": achieved_tf / MFMA_F32_PEAK_TFLOPS,
             "traffic": measured_traffic(name, "ppo2hip::mlp_fused16_kernel<5, false, 2>") if fused else
