@@ -33,6 +33,27 @@ def test_gemm_f32(hip, M, N, K):
     assert np.all(np.abs(C - ref) <= 2e-6 * scale + 1e-30)   # fp32 fma chain, K up to 3000
 
 
+@pytest.mark.parametrize("M,N,K,positive", [(2048, 512, 3136, False), (2048, 512, 3136, True), (4096, 64, 512, True),
+                                            (1024, 192, 4096, True), (1111, 100, 1024, False)])
+def test_gemm_f32_wide_shapes_on_the_bf16_pipe(hip, M, N, K, positive):
+    """The shapes that take the bf16-piece products (128-row tiles, more than 32 columns, K a multiple of 16): float32
+    results from six exact piece products per multiply-add.  Same-signed operands are the adversarial case: nothing
+    cancels, so a biased cut (all three pieces truncated) shows as a drift of the whole sum — the mean signed error must
+    stay at the float32 chain's level, not only the maximum."""
+    rng = np.random.RandomState(M + N + K)
+    draw = (lambda *s: rng.rand(*s)) if positive else (lambda *s: rng.randn(*s))
+    A = draw(M, K).astype(np.float32)
+    B = draw(K, N).astype(np.float32)
+    C = hip.gemm(dev(A), dev(B)).cpu().numpy().astype(np.float64)
+    again = hip.gemm(dev(A), dev(B)).cpu().numpy()
+    assert np.array_equal(C.astype(np.float32), again)          # fixed summation order
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    scale = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    rel = (C - ref) / scale
+    assert np.abs(rel).max() <= 4e-6                             # float32 pipe on the same data: 4.0e-6 at K = 3136
+    assert np.abs(rel).mean() <= 1e-6 and abs(rel.mean()) <= 3e-7
+
+
 CASES = ["small", "mid", "cartpole_shape", "nodone", "alldone"]
 
 
