@@ -34,9 +34,13 @@ namespace ppo2hip {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 // 16 x 16 x 32 product of bf16 operands (eight per lane and operand, k = 8 lk .. 8 lk + 7), float32 accumulate
 #define MFMA32B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+// 32 x 32 x 16 product of bf16 operands (lane l: row / column l & 31, k = the eight values of half l >> 5), float32 accumulate:
+// result register r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
+#define MFMA16Q(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
 namespace f16 {
 constexpr int kThreads = 512;
@@ -173,6 +177,11 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
 #define LDSQ(base, q, m, p) (*(const uint4 *)(lds + (base) + 4 * ((((q) * 4 + (m)) * 3 + (p)) * 64 + lane)))
 
     constexpr int PB = WIDE ? 1 : 2;      // accumulator blocks a piece product serves at a time (register budget)
+    // Layer 2's weight gradient h1^T dz2 contracts over the tile's 16 samples: as 32 x 32 x 16 bf16 products (2 x 2
+    // blocks, six piece products each) it takes 24 matrix instructions that leave the vector ALUs free for all but 8 of
+    // their 32 cycles, where the float32 form takes 64 of 32 cycles that block them; the operands are the rows the
+    // float32 form reads from the tiles, cut in registers (8 values per lane and 32-row block).
+    constexpr bool DW2Q = !WIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const bool is_value = (int)blockIdx.x >= g.nwg_policy;
@@ -310,6 +319,8 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
     // 16-byte chunk {samples lk, lk + 4, lk + 8, lk + 12} of row 16 m + li: swz = (li >> 2) & 2
     const int rpos = li * 16 + ((lk ^ ((li >> 2) & 2)) << 2);           // + 256 m
     const int wpos = (lk * 64 + li) * 4;                                // lane part of the packed 64-wide weight reads
+    // the two adjacent 16-byte chunks {2 hh, 2 hh + 1} of row 32 b + (lane & 31): swz = (row >> 2) & 2
+    const int qpos = (lane & 31) * 16 + ((((lane >> 5) << 1) ^ (((lane & 31) >> 2) & 2)) << 2);      // + 512 b, + 4 for the second chunk
 
     // advantage normalisation constants (baselines/ppo2/common_functions.py:67)
     double adv_mean = 0.0, adv_rstd = 1.0;
@@ -342,8 +353,9 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
     }
 
     // ---- gradient accumulators (registers, whole launch) ------------------------------------
-    f32x4 dW1[2][HB], dW2[HB][HB], dWh[HB];
-    float db2[HB], dbh = 0.f;
+    f32x4 dW1[2][HB], dW2[DW2Q ? 1 : HB][DW2Q ? 1 : HB], dWh[HB];
+    f32x16 dW2q[DW2Q ? 2 : 1][DW2Q ? 2 : 1];      // block (bi, bj) = input units 32 bi .., output units 32 bj ..
+    float db2[HB], dbh = 0.f;                     // DW2Q: db2[bj] = this lane's share of unit 32 bj + (lane & 31)
     float dx16[HB], db1[HB];          // XV: rows 16 (feature x16) and ob_dim (ones) of dW1, per lane over its four samples
 #pragma unroll
     for (int a = 0; a < HB; a++) {
@@ -356,9 +368,15 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
             dW1[0][a][r] = 0.f;
             dW1[1][a][r] = 0.f;
 #pragma unroll
-            for (int b = 0; b < HB; b++) dW2[a][b][r] = 0.f;
+            for (int b = 0; b < (DW2Q ? 1 : HB); b++) dW2[DW2Q ? 0 : a][b][r] = 0.f;
         }
     }
+#pragma unroll
+    for (int a = 0; a < (DW2Q ? 2 : 1); a++)
+#pragma unroll
+        for (int b = 0; b < (DW2Q ? 2 : 1); b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) dW2q[a][b][r] = 0.f;
     // per-lane loss sums stay short (one term per tile): float here, double from the wave sum on
     float s_pg = 0.f, s_vf = 0.f, s_ent = 0.f, s_kl = 0.f, s_cf = 0.f;
 
@@ -679,7 +697,26 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
             dz1[mb] = neg_times_tanh_grad4(dz1[mb], t);    // -(W2 (-dz2)) tanh' = dz1
         }
         // ---- layer 2: weight gradient (h1^T dz2 from the tiles), bias gradient from the same operand reads ---
-        {
+        if constexpr (DW2Q) {
+            // lane (r32, hh) takes row 32 b + r32 of a tile and the sample chunks 2 hh, 2 hh + 1 (samples c + 4 j of
+            // chunk c: any split of the sixteen samples over the lane halves serves, h1 and dz2 use the same one)
+            uint4 ap[2][3];
+#pragma unroll
+            for (int bi = 0; bi < 2; bi++)
+                cut8(LDS4(WEIGHTS + wave * WAVE + TA + qpos + 512 * bi), LDS4(WEIGHTS + wave * WAVE + TA + qpos + 4 + 512 * bi), ap[bi][0], ap[bi][1], ap[bi][2]);
+#pragma unroll
+            for (int bj = 0; bj < 2; bj++) {
+                const f32x4 v0 = LDS4(WEIGHTS + wave * WAVE + TB + qpos + 512 * bj), v1 = LDS4(WEIGHTS + wave * WAVE + TB + qpos + 4 + 512 * bj);
+                db2[bj] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+                uint4 bp[3];
+                cut8(v0, v1, bp[0], bp[1], bp[2]);
+                constexpr int pa_[6] = {2, 0, 1, 1, 0, 0}, pb_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; t++)
+#pragma unroll
+                    for (int bi = 0; bi < 2; bi++) dW2q[bi][bj] = MFMA16Q(ap[bi][pa_[t]], bp[pb_[t]], dW2q[bi][bj]);
+            }
+        } else {
             f32x4 a[HB], b[HB];
 #pragma unroll
             for (int m = 0; m < HB; m++) {
@@ -787,12 +824,22 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
             }
         }
         // dW2 and db2 were accumulated from -dz2 (see neg_times_tanh_grad4)
+        if constexpr (DW2Q) {
+#pragma unroll
+            for (int bi = 0; bi < 2; bi++)
+#pragma unroll
+                for (int bj = 0; bj < 2; bj++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        st(S_W2 + (32 * bi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * H + 32 * bj + (lane & 31), -dW2q[bi][bj][r]);
+        } else {
 #pragma unroll
         for (int mi = 0; mi < HB; mi++)
 #pragma unroll
             for (int mj = 0; mj < HB; mj++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) st(S_W2 + (16 * mi + 4 * lk + r) * H + 16 * mj + li, -dW2[mi][mj][r]);
+        }
         if (vhead) {
 #pragma unroll
             for (int mi = 0; mi < HB; mi++)
@@ -805,10 +852,18 @@ __global__ __launch_bounds__(f16::kThreads, 2) void mlp_fused16_kernel(Fused16Ar
 #pragma unroll
                 for (int r = 0; r < 4; r++) st(S_WH + (16 * mi + 4 * lk + r) * 16 + li, dWh[mi][r]);
         }
+        if constexpr (DW2Q) {
+#pragma unroll
+            for (int bj = 0; bj < 2; bj++) {
+                const float v = db2[bj] + __shfl_xor(db2[bj], 32, 64);          // the two sample halves
+                if (lane < 32) st(S_B2 + 32 * bj + lane, -v);
+            }
+        } else {
 #pragma unroll
         for (int mj = 0; mj < HB; mj++) {
             const float v = quarters(db2[mj]);
             if (lk == 0) st(S_B2 + 16 * mj + li, -v);
+        }
         }
         const float v = quarters(dbh);
         if (vhead) {
