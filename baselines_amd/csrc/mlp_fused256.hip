@@ -24,7 +24,12 @@
 namespace ppo2hip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+typedef short bf16x8v __attribute__((ext_vector_type(8)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// 32 x 32 x 16 product of bf16 operands (lane l: row / column l & 31, k = the eight values of half l >> 5), float32 accumulate:
+// result register r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
+#define MFMA16Q(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, (a)), __builtin_bit_cast(bf16x8v, (b)), (c), 0, 0, 0)
 
 namespace f256 {
 constexpr int kThreads = 512, kWaves = 8;
@@ -559,13 +564,21 @@ __global__ __launch_bounds__(w256::kThreads, 2) void mlp_wgrad256_kernel(Wgrad25
         if (tid < 256) st[oDO + r16 * PO + c16] = pDO;
     };
 
-    f32x4 acc2[4][4], acc1[2][2], acch, accb2, accbh;
+    // dW2 runs on the bf16 matrix pipe as exact piece products (cut_run8 of gemm_core.hpp: three bf16 pieces per value, six
+    // products per multiply-add): a slab's 16 samples are the k of one v_mfma_f32_32x32x16_bf16, so a wave's 64 x 64
+    // share of dW2 is 2 x 2 blocks of 6 instructions per slab that leave the vector ALUs free for all but 8 of their 32
+    // cycles, where the float32 form took 64 instructions of 32 cycles that block them.  The other sums are too small
+    // for the 32 x 32 shape and stay float32.
+    f32x16v acc2[2][2];
+    f32x4 acc1[2][2], acch, accb2, accbh;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[a][b][r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) acc2[a][b][r] = 0.f;
 #pragma unroll
         for (int f = 0; f < 2; f++)
 #pragma unroll
@@ -575,28 +588,48 @@ __global__ __launch_bounds__(w256::kThreads, 2) void mlp_wgrad256_kernel(Wgrad25
     const int wr = wave >> 1, wc = wave & 1;
     const float ones_row = li == 0 ? 1.f : 0.f;
     // lane bases (floats) of the operand reads inside a stage; + (4 kk) rows per k-step
-    const int bA2 = oH1 + lk * P1 + 64 * wr + li, bB2 = oDZ2 + lk * P2 + 64 * wc + li;
+    // dW2 operands: lane (l32, hh) takes column 64 wr + 32 a + l32 of the h1 tile (64 wc + 32 b + l32 of the dz2 tile) and
+    // the slab's sample rows 2 hh + {0, 1, 4, 5, 8, 9, 12, 13} (any split of the sixteen over the lane halves serves; both
+    // operands use the same one, and with pitches of 16 mod 64 floats rows two apart put the halves on different banks)
+    const int l32 = lane & 31, hh = lane >> 5;
+    const int bA2 = oH1 + 2 * hh * P1 + 64 * wr + l32, bB2 = oDZ2 + 2 * hh * P2 + 64 * wc + l32;
     const int bA1 = oX + lk * PX + li, bB1 = oDZ1 + lk * P1 + 32 * wave + li;
     const int bAh = oH2 + lk * P2 + 16 * wave + li, bBh = oDO + lk * PO + li, bBb = oDZ2 + lk * P2 + 16 * wave + li;
 
     // operand registers of one k-step (four sample rows): 4 + 4 for dW2, 2 + 2 for dW1, head unit block, dout, dz2 block
-    struct Ops { float a2[4], b2[4], a1[2], b1[2], ah, bh, bb; };
+    struct Ops { float a1[2], b1[2], ah, bh, bb; };
     auto read_ops = [&](const float *st, int kk, Ops &o) {
-#pragma unroll
-        for (int a = 0; a < 4; a++) o.a2[a] = st[bA2 + 4 * kk * P1 + 16 * a];
-#pragma unroll
-        for (int b = 0; b < 4; b++) o.b2[b] = st[bB2 + 4 * kk * P2 + 16 * b];
 #pragma unroll
         for (int f = 0; f < 2; f++) o.a1[f] = st[bA1 + 4 * kk * PX + 16 * f];
 #pragma unroll
         for (int c = 0; c < 2; c++) o.b1[c] = st[bB1 + 4 * kk * P1 + 16 * c];
         o.ah = st[bAh + 4 * kk * P2]; o.bh = st[bBh + 4 * kk * PO]; o.bb = st[bBb + 4 * kk * P2];
     };
+    // the slab's dW2 products: A blocks cut first, then one B block at a time
+    auto multiply2 = [&](const float *st) {
+        uint4 ap[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = st[bA2 + ((j & 1) + 4 * (j >> 1)) * P1 + 32 * a];
+            cut_run8(v, ap[a]);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = st[bB2 + ((j & 1) + 4 * (j >> 1)) * P2 + 32 * b];
+            uint4 bp[3];
+            cut_run8(v, bp);
+            constexpr int pa[6] = {2, 0, 1, 1, 0, 0}, pb[6] = {0, 2, 1, 0, 1, 0};      // small products first
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+#pragma unroll
+                for (int a = 0; a < 2; a++) acc2[a][b] = MFMA16Q(ap[a][pa[t]], bp[pb[t]], acc2[a][b]);
+        }
+    };
     auto multiply = [&](const Ops &o) {
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) acc2[a][b] = MFMA16(o.a2[a], o.b2[b], acc2[a][b]);
 #pragma unroll
         for (int f = 0; f < 2; f++)
 #pragma unroll
@@ -618,6 +651,7 @@ __global__ __launch_bounds__(w256::kThreads, 2) void mlp_wgrad256_kernel(Wgrad25
         const float *st = lds + buf * STAGE;
         Ops o[2];
         read_ops(st, 0, o[0]);
+        multiply2(st);
 #pragma unroll
         for (int kk = 0; kk < KS / 4; kk++) {
             if (kk + 1 < KS / 4) read_ops(st, kk + 1, o[(kk + 1) & 1]);
@@ -637,11 +671,14 @@ __global__ __launch_bounds__(w256::kThreads, 2) void mlp_wgrad256_kernel(Wgrad25
     // ---- this workgroup's slab: result register r of lane (li, lk) = row 4 lk + r, column li of its block ---------------
     float *slab = g.slabs + ((int64_t)trunk * kSlabsPerTrunk + wg) * SLAB;
 #pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                slab[S2 + (64 * wr + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hh) * 128 + 64 * wc + 32 * b + l32] = acc2[a][b][r];
+#pragma unroll
     for (int r = 0; r < 4; r++) {
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) slab[S2 + (64 * wr + 16 * a + 4 * lk + r) * 128 + 64 * wc + 16 * b + li] = acc2[a][b][r];
 #pragma unroll
         for (int f = 0; f < 2; f++)
 #pragma unroll

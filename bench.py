@@ -313,6 +313,12 @@ def gradient_roofline(name, cfg, B, grad_ms):
         h = cfg["hidden"][0]
         f_bf16 = 3 * 2 * (2 * h * h) * B
         peak_tf = flops_mb / ((flops_mb - f_bf16) / MFMA_F32_PEAK_TFLOPS + 6 * f_bf16 / MFMA_BF16_PEAK_TFLOPS)
+    if fused256:
+        # layer 2's weight gradient of both trunks (2 x 2 H1 H2 flops per sample) runs on the bf16 pipe as six piece
+        # products per multiply-add, the rest on the float32 pipe
+        h1, h2 = cfg["hidden"]
+        f_bf16 = 2 * (2 * h1 * h2) * B
+        peak_tf = flops_mb / ((flops_mb - f_bf16) / MFMA_F32_PEAK_TFLOPS + 6 * f_bf16 / MFMA_BF16_PEAK_TFLOPS)
     if image:
         # every wide product runs on the bf16 pipe: conv1 at three piece products per multiply-add (its uint8 operand is
         # one piece), the others at six; the recurrent h . Wh products of the sequence kernels stay on the float32
@@ -326,7 +332,9 @@ def gradient_roofline(name, cfg, B, grad_ms):
                        "exact piece products per multiply-add; peak = algorithmic flops over the time the two matrix pipes need at "
                        "their dense rates)") if fused else
                       ("ppo_grad = gather + mlp_fused256_kernel (forward, loss, input gradients) + mlp_wgrad256_kernel "
-                       "(all weight gradients) + slab reduction, fp32 MFMA") if fused256 else
+                       "(all weight gradients; layer 2's on the bf16 pipe as six exact piece products per multiply-add) + slab "
+                       "reduction, otherwise fp32 MFMA; peak = algorithmic flops over the time the two matrix pipes need at "
+                       "their dense rates") if fused256 else
                       ("ppo_grad = gather + layered GEMM / implicit-GEMM conv launches (bf16 pipe: six exact piece products per "
                        "float32 multiply-add, three for conv1 on uint8 frames; float32 pipe for the recurrent products of the "
                        "sequence kernels) + loss + slab reductions; peak = algorithmic flops over the time the two matrix "
