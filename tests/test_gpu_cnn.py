@@ -192,6 +192,35 @@ def test_uint8_conv_kernels_agree_with_the_float32_route(tmp_path):
     np.testing.assert_allclose(out["pieces"]["losses"][:5], out["plain"]["losses"][:5], rtol=2e-6, atol=1e-7)
 
 
+def test_piece_products_agree_with_the_float32_pipe(tmp_path):
+    """The wide convolution products on the bf16 pipe (six exact piece products per multiply-add) against the same launches
+    on the float32 pipe (PPO2HIP_GEMM_FP32=1, read once per process): same inputs, two fresh processes.  Both are exact
+    up to the rounding of running sums, so the nature_cnn gradients agree to 5e-6 of each variable's largest entry."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "route.py"
+    script.write_text(_ROUTE_SCRIPT)
+    out = {}
+    for name, env in (("pieces", {}), ("fp32", {"PPO2HIP_GEMM_FP32": "1"})):
+        e = dict(os.environ)
+        e.update(env)
+        path = str(tmp_path / (name + ".npz"))
+        subprocess.run([sys.executable, str(script), root, path], check=True, env=e, timeout=240)
+        out[name] = np.load(path)
+    from baselines_amd import hip as h, _lib
+    spec = h.PolicySpec(_lib.POLICY_CNN, _lib.DIST_CATEGORICAL, 6, 1, ob_hwc=(84, 84, 4))
+    a, b = out["pieces"]["grads"], out["fp32"]["grads"]
+    assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
+    assert not np.array_equal(a, b)          # the switch did change the route
+    for name, off, shp in spec.vars:
+        n = int(np.prod(shp))
+        ref = b[off:off + n]
+        assert np.abs(a[off:off + n] - ref).max() <= 5e-6 * max(np.abs(ref).max(), 1e-6), name
+    np.testing.assert_allclose(out["pieces"]["losses"][:5], out["fp32"]["losses"][:5], rtol=5e-6, atol=1e-7)
+
+
 _LSTM_ROUTE_SCRIPT = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
